@@ -1,0 +1,641 @@
+"""epidemicsimulator_amd -- MI355X engine for the metapopulation step and the beta x travel
+calibration sweep, behind the reference's own API names.
+
+Python here is only the host-side mirror of the reference interface (same class and method
+names, argument meaning and error behaviour as the Scala sources under
+src/main/scala/epidemic/); all arithmetic of the path runs in libepi.so on the GPU.
+"""
+import ctypes as C
+import enum
+import math
+from dataclasses import dataclass, field, replace
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _capi
+from ._capi import (EpiError, IllegalArgumentException, EPI_OK, check, f64, i32, lib, ptr)
+
+__all__ = ["Action", "State", "HyperParams", "TrainConfig", "Geo", "ToyConn", "EpidemicEnv", "WorldToy",
+           "Calibrate", "Validation", "GridEngine", "EpiError", "IllegalArgumentException"]
+
+
+# ------------------------------------------------------------------------------------------------
+# env.scala:6-30
+# ------------------------------------------------------------------------------------------------
+class Action(enum.IntEnum):
+    NoneA = 0
+    Distancing = 1
+    TravelBan = 2
+    Lockdown = 3
+    NormalCare = 4
+    SurgeCare = 5
+    TargetedVax = 6
+    MassVax = 7
+
+    @staticmethod
+    def from_id(i: int) -> "Action":  # env.scala:18-20
+        return Action(max(0, min(7, int(i))))
+
+
+@dataclass
+class State:  # env.scala:22-30
+    s: float
+    i: float
+    r: float
+    d: float
+    v: float
+    hosp_cap: float
+    t: int
+    t_max: int
+    seed: int = 0
+
+    @property
+    def n(self) -> float:
+        return self.s + self.i + self.r + self.d
+
+    @property
+    def util(self) -> float:
+        return self.i / max(1.0, self.hosp_cap)
+
+    def features(self) -> List[float]:
+        N = max(1.0, self.n)
+        return [self.s / N, self.i / N, self.r / N, self.d / N, self.v / N, self.util,
+                float(self.t) / max(1, self.t_max)]
+
+    def copy(self, **kw) -> "State":
+        return replace(self, **kw)
+
+    def _c(self) -> _capi.CState:
+        return _capi.CState(float(self.s), float(self.i), float(self.r), float(self.d), float(self.v),
+                            float(self.hosp_cap), int(self.t), int(self.t_max), int(self.seed), 0)
+
+    @staticmethod
+    def _from_c(c) -> "State":
+        return State(c.s, c.i, c.r, c.d, c.v, c.hosp_cap, c.t, c.t_max, c.seed)
+
+
+@dataclass
+class HyperParams:  # config.scala:3-21
+    gamma: float = 0.99
+    lr: float = 1e-3
+    epsilon_start: float = 1.0
+    epsilon_end: float = 0.1
+    epsilon_decay_steps: int = 100000
+    target_update_every: int = 1500
+    replay_capacity: int = 50000
+    batch_size: int = 128
+    hidden: int = 128
+    clip_q: float = 10.0
+    reward_clip: float = 5.0
+    grad_clip: float = 1.0
+    log_interval: int = 500
+    ema_alpha: float = 0.0
+    checkpoint: bool = True
+    learn_every: int = 8
+
+    def _c(self) -> _capi.CHyper:
+        return _capi.CHyper(self.epsilon_start, self.epsilon_end, self.epsilon_decay_steps, self.hidden, self.clip_q,
+                            self.reward_clip, self.batch_size, self.learn_every)
+
+
+@dataclass
+class TrainConfig:  # config.scala:23-27
+    epochs: int = 1000
+    steps_per_epoch: int = 500
+    eval_every: int = 10
+
+
+# ------------------------------------------------------------------------------------------------
+# Geo.scala
+# ------------------------------------------------------------------------------------------------
+class Geo:
+    @dataclass
+    class Country:  # Geo.scala:4-21
+        name: str
+        pop: int
+        lat: float
+        lon: float
+        hosp_per_1k: float = 3.0
+        beta_mul: float = 1.0
+        ifr_mul: float = 1.0
+        noise: float = 0.05
+        population_density: float = 100.0
+        gdp_per_capita: float = 30000.0
+        healthcare_capacity: float = 0.7
+        mobility_index: float = 0.8
+        age_distribution_elderly: float = 0.15
+        climate_factor: float = 0.6
+        connectivity_strength: float = 0.8
+        economic_resilience: float = 0.7
+
+        def _c(self) -> _capi.Profile:
+            return _capi.Profile(self.beta_mul, self.ifr_mul, self.noise, self.population_density,
+                                 self.gdp_per_capita, self.healthcare_capacity, self.age_distribution_elderly,
+                                 self.connectivity_strength, self.economic_resilience)
+
+    class CountryProfiles:  # Geo.scala:23-69
+        _TABLE = {
+            "USA": ("USA", 331000000, 39.8, -98.5, 2.9, 1.0, 1.0, 0.05, 36.0, 65000.0, 0.85, 0.9, 0.20, 0.7, 0.95, 0.9),
+            "Japan": ("Japan", 125000000, 36.2, 138.2, 13.1, 0.8, 0.9, 0.03, 347.0, 42000.0, 0.95, 0.6, 0.30, 0.5, 0.8, 0.8),
+            "India": ("India", 1380000000, 20.6, 78.9, 0.5, 1.3, 1.2, 0.08, 464.0, 2100.0, 0.3, 0.4, 0.07, 0.8, 0.4, 0.3),
+            "Italy": ("Italy", 60000000, 41.9, 12.6, 3.2, 1.1, 1.4, 0.04, 206.0, 35000.0, 0.8, 0.7, 0.28, 0.6, 0.85, 0.7),
+            "Germany": ("Germany", 83000000, 51.2, 10.5, 8.0, 0.9, 0.8, 0.03, 240.0, 46000.0, 0.9, 0.8, 0.25, 0.4, 0.9, 0.85),
+            "China": ("China", 1400000000, 35.9, 104.2, 4.3, 1.0, 1.0, 0.06, 153.0, 10500.0, 0.6, 0.5, 0.18, 0.7, 0.7, 0.6),
+        }
+
+        @staticmethod
+        def get_profile(name: str) -> "Geo.Country":
+            row = Geo.CountryProfiles._TABLE.get(name)
+            if row is None:
+                return Geo.Country(name, 50000000, 0.0, 0.0)  # default fallback, Geo.scala:67
+            return Geo.Country(*row)
+
+    @staticmethod
+    def haversine_km(lat1, lon1, lat2, lon2) -> float:  # Geo.scala:72-79
+        R = 6371.0
+        d_lat = math.radians(lat2 - lat1)
+        d_lon = math.radians(lon2 - lon1)
+        a = math.pow(math.sin(d_lat / 2), 2) + math.cos(math.radians(lat1)) * math.cos(math.radians(lat2)) * math.pow(
+            math.sin(d_lon / 2), 2)
+        c = 2 * math.atan2(math.sqrt(a), math.sqrt(1 - a))
+        return R * c
+
+
+# ------------------------------------------------------------------------------------------------
+# ToyConn.scala
+# ------------------------------------------------------------------------------------------------
+class ToyConn:
+    C: List[Geo.Country] = [  # ToyConn.scala:7-14 (positional: hospPer1k, betaMul, ifrMul, noise)
+        Geo.Country("USA", 330_000_000, 38.0, -97.0, 2.9, 1.00, 1.00, 0.05),
+        Geo.Country("Japan", 125_000_000, 36.0, 138.0, 7.8, 0.92, 0.90, 0.04),
+        Geo.Country("Italy", 60_000_000, 42.5, 12.5, 3.2, 0.98, 1.05, 0.05),
+        Geo.Country("India", 1_420_000_000, 22.0, 79.0, 0.7, 1.05, 0.95, 0.06),
+        Geo.Country("Germany", 83_000_000, 51.0, 10.0, 8.0, 0.96, 0.95, 0.04),
+        Geo.Country("China", 1_410_000_000, 35.0, 103.0, 4.3, 1.03, 1.00, 0.05),
+    ]
+    flight_mul: Dict[Tuple[str, str], float] = {  # ToyConn.scala:16-20
+        ("China", "India"): 1.8, ("India", "China"): 1.2, ("USA", "Japan"): 1.6, ("Japan", "USA"): 1.6,
+        ("Germany", "Italy"): 1.3, ("Italy", "Germany"): 1.2}
+
+    @staticmethod
+    def gravity_matrix(countries, a=0.2, b=1.0, g=1.2, k=1e-6, cap_row=0.12) -> np.ndarray:
+        """ToyConn.scala:22-47.  Built with the host libm: the JVM's Math.pow/sin/cos may differ in the
+        last ulp, so the matrix is an engine INPUT rather than something the engine reproduces."""
+        n = len(countries)
+        W = np.zeros((n, n))
+        for i, ci in enumerate(countries):
+            row_sum = 0.0
+            for j, cj in enumerate(countries):
+                if i != j:
+                    d = max(300.0, Geo.haversine_km(ci.lat, ci.lon, cj.lat, cj.lon))
+                    f = ToyConn.flight_mul.get((ci.name, cj.name), 1.0)
+                    w = k * math.pow(float(ci.pop), a) * math.pow(float(cj.pop), b) * f / math.pow(d, g)
+                    W[i, j] = w
+                    row_sum += w
+            if row_sum > 0:
+                scale = min(1.0, cap_row / row_sum)
+                for j in range(n):
+                    if i != j:
+                        W[i, j] *= scale
+            W[i, i] = 0.0
+        return W
+
+    @staticmethod
+    def scale_edge(W, src: int, dst: int, factor: float) -> np.ndarray:  # ToyConn.scala:51-55
+        A = np.array(W, dtype=np.float64, copy=True)
+        A[src, dst] *= factor
+        return A
+
+    @staticmethod
+    def scale_row(W, row: int, factor: float) -> np.ndarray:  # ToyConn.scala:58-70
+        A = f64(W)
+        out = np.empty_like(A)
+        check(lib().epi_scale_row(ptr(A, C.c_double), C.c_int32(A.shape[0]), C.c_int32(row), C.c_double(factor),
+                                  ptr(out, C.c_double)))
+        return out
+
+
+ToyConn.W = ToyConn.gravity_matrix(ToyConn.C)
+ToyConn.W2 = ToyConn.scale_edge(ToyConn.W, 5, 3, 3.0)  # ToyConn.scala:56
+
+
+# ------------------------------------------------------------------------------------------------
+# Validation.scala
+# ------------------------------------------------------------------------------------------------
+class Validation:
+    @dataclass
+    class Invariants:
+        pop: int
+        t_max: int
+
+    @dataclass
+    class Metrics:
+        arrival: int
+        peak_i: float
+        final_i: float
+
+    @staticmethod
+    def _require(cond: bool, msg: str):
+        if not cond:
+            raise IllegalArgumentException(_capi.EPI_ERR_ASSERT_STATE, "requirement failed: " + msg)
+
+    @staticmethod
+    def assert_state(s: State, inv: "Validation.Invariants") -> None:  # Validation.scala:6-11
+        Validation._require(s.s >= 0 and s.i >= 0 and s.r >= 0 and s.d >= 0 and s.v >= 0, "neg compartment: %s" % (s,))
+        total = s.s + s.i + s.r + s.d + s.v
+        Validation._require(int(math.floor(total + 0.5)) == inv.pop, "mass not conserved: %s != %s" % (total, inv.pop))
+        Validation._require(0 <= s.t <= inv.t_max, "t out of bounds: %d not in [0, %d]" % (s.t, inv.t_max))
+
+    @staticmethod
+    def arrival_time(i_series: Sequence[float], thresh: float = 10.0) -> int:  # Validation.scala:15-19
+        for k, v in enumerate(i_series):
+            if v >= thresh:
+                return k
+        return len(i_series)
+
+    @staticmethod
+    def peak_i(i_series: Sequence[float]) -> float:  # Validation.scala:21-22
+        return 0.0 if len(i_series) == 0 else max(i_series)
+
+
+# ------------------------------------------------------------------------------------------------
+# JVM-compatible streams held on the host side of the boundary
+# ------------------------------------------------------------------------------------------------
+class _GaussStream:
+    """scala.util.Random(seed).nextGaussian() sequence (env.scala:42,91), extended on demand."""
+
+    def __init__(self, seed: int):
+        self.seed, self.pos, self.buf = int(seed), 0, np.zeros(0)
+
+    def next(self) -> float:
+        if self.pos >= len(self.buf):
+            n = max(64, 2 * len(self.buf))
+            out = np.zeros(n)
+            check(lib().epi_java_gaussians(C.c_int64(self.seed), C.c_int32(n), ptr(out, C.c_double)))
+            self.buf = out
+        v = float(self.buf[self.pos])
+        self.pos += 1
+        return v
+
+
+class _AgentStream:
+    """Action choice of a never-trained DDQNAgent (DDQNAgent.scala:12-32); -1 marks the argmax-Q branch."""
+
+    def __init__(self, hp: HyperParams):
+        self.hp, self.pos, self.buf = hp, 0, np.zeros(0, dtype=np.int32)
+
+    def next(self) -> int:
+        if self.pos >= len(self.buf):
+            n = max(256, 2 * len(self.buf))
+            out = np.zeros(n, dtype=np.int32)
+            chp = self.hp._c()
+            check(lib().epi_agent_actions(C.byref(chp), C.c_int32(n), ptr(out, C.c_int32)))
+            self.buf = out
+        v = int(self.buf[self.pos])
+        self.pos += 1
+        return v
+
+
+def mlp_init(hidden: int = 128):
+    """Untrained network of MLP.scala:5-9."""
+    W1 = np.zeros((hidden, 7)); W2 = np.zeros((hidden, hidden)); W3 = np.zeros((8, hidden))
+    check(lib().epi_mlp_init(7, hidden, 8, ptr(W1, C.c_double), ptr(W2, C.c_double), ptr(W3, C.c_double)))
+    return W1, W2, W3
+
+
+def mlp_greedy(states: Sequence[State], weights, clip_q: float = 10.0):
+    """DDQNAgent.actGreedy for a batch of states: (q[B][8], action[B])."""
+    W1, W2, W3 = (f64(w) for w in weights)
+    arr = (_capi.CState * len(states))(*[s._c() for s in states])
+    q = np.zeros((len(states), 8)); act = np.zeros(len(states), dtype=np.int32)
+    check(lib().epi_mlp_greedy_batch(arr, C.c_int32(len(states)), C.c_int32(W1.shape[0]), ptr(W1, C.c_double), None,
+                                     ptr(W2, C.c_double), None, ptr(W3, C.c_double), None, C.c_double(clip_q),
+                                     ptr(q, C.c_double), ptr(act, C.c_int32)))
+    return q, act
+
+
+# ------------------------------------------------------------------------------------------------
+# env.scala:32-255
+# ------------------------------------------------------------------------------------------------
+class EpidemicEnv:
+    def __init__(self, base_beta=0.35, base_gamma=0.12, base_ifr=0.008, noise=0.05, reward_clip=5.0, risk_factor=0.0,
+                 country_name="Unknown", seed=42, profile: Optional[Geo.Country] = None):
+        self.base_beta, self.base_gamma, self.base_ifr, self.noise = base_beta, base_gamma, base_ifr, noise
+        self.reward_clip, self.risk_factor, self.country_name, self.seed = reward_clip, risk_factor, country_name, seed
+        self.country_profile = profile if profile is not None else Geo.CountryProfiles.get_profile(country_name)
+        self._rnd = _GaussStream(seed)
+
+    def reset(self, s0: State) -> State:
+        return s0
+
+    def _c(self) -> _capi.EnvParams:
+        return _capi.EnvParams(self.base_beta, self.base_gamma, self.base_ifr, self.noise, self.reward_clip,
+                               self.risk_factor)
+
+    @dataclass
+    class EnvParams:
+        beta: float
+        gamma: float
+        ifr: float
+        noise: float
+
+    @property
+    def params(self) -> "EpidemicEnv.EnvParams":  # env.scala:236-237
+        return EpidemicEnv.EnvParams(self.base_beta, self.base_gamma, self.base_ifr, self.noise)
+
+    def step(self, st: State, act) -> Tuple[State, float, bool]:  # env.scala:58-140
+        nxt, r, d = EpidemicEnv.step_batch([self], [st], [int(act)], [self._rnd.next()])
+        return nxt[0], float(r[0]), bool(d[0])
+
+    @staticmethod
+    def step_batch(envs, states, actions, gauss):
+        """B independent EpidemicEnv.step calls in one launch (epi_env_step_batch)."""
+        B = len(envs)
+        env_arr = (_capi.EnvParams * B)(*[e._c() for e in envs])
+        prof_arr = (_capi.Profile * B)(*[e.country_profile._c() for e in envs])
+        st_arr = (_capi.CState * B)(*[s._c() for s in states])
+        out = (_capi.CState * B)()
+        a = i32(actions); g = f64(gauss)
+        r = np.zeros(B); d = np.zeros(B, dtype=np.uint8)
+        check(lib().epi_env_step_batch(env_arr, prof_arr, st_arr, ptr(a, C.c_int32), ptr(g, C.c_double), out,
+                                       ptr(r, C.c_double), ptr(d, C.c_uint8), C.c_int32(B)))
+        return [State._from_c(o) for o in out], r, d
+
+    @staticmethod
+    def allocate_int(total: int, weights: Sequence[float]) -> List[int]:  # env.scala:241-254
+        w = f64(weights)
+        out = np.zeros(len(w), dtype=np.int32)
+        check(lib().epi_alloc_int(C.c_int32(int(total)), ptr(w, C.c_double), C.c_int32(len(w)), ptr(out, C.c_int32)))
+        return out.tolist()
+
+    @staticmethod
+    def allocate_int_batch(totals, weights) -> np.ndarray:
+        w = f64(weights); t = i32(totals)
+        out = np.zeros(w.shape, dtype=np.int32)
+        check(lib().epi_alloc_int_batch(ptr(t, C.c_int32), ptr(w, C.c_double), C.c_int32(w.shape[1]),
+                                        C.c_int32(w.shape[0]), ptr(out, C.c_int32)))
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# WorldToy.scala
+# ------------------------------------------------------------------------------------------------
+def _csr_or_dense(conn):
+    """Accepts a dense 2-D array or a (rowptr, col, val) triple."""
+    if isinstance(conn, tuple):
+        rp, col, val = i32(conn[0]), i32(conn[1]), f64(conn[2])
+        return None, rp, col, val
+    return f64(conn), None, None, None
+
+
+class WorldToy:
+    """WorldToy.scala:11-235 with the country list as an input (default ToyConn.C) and an optional
+    `batch` of identical, independently evolving instances stepped in one launch."""
+
+    @dataclass
+    class Node:
+        idx: int
+        name: str
+        pop: int
+        env: EpidemicEnv
+        hyper_params: HyperParams
+        s: State
+        last_a: int = 0
+
+    def __init__(self, hp: HyperParams, base: State, seed_idx: int = 0, conn=None,
+                 make_env: Callable[[], EpidemicEnv] = lambda: EpidemicEnv(),
+                 make_env_for: Optional[Callable[[str, int], EpidemicEnv]] = None, validate: bool = False,
+                 countries: Optional[Sequence[Geo.Country]] = None, batch: int = 1, device: int = 0):
+        self.hp, self.base, self.seed_idx, self.validate, self.batch = hp, base, seed_idx, validate, batch
+        self.countries = list(countries) if countries is not None else list(ToyConn.C)
+        n = self.n = len(self.countries)
+        conn = ToyConn.W if conn is None else conn
+        envs = [make_env_for(c.name, c.pop) if make_env_for else make_env() for c in self.countries]
+        self._envs = envs
+        pops = i32([c.pop for c in self.countries])
+        dense, rp, col, val = _csr_or_dense(conn)
+        env_arr = (_capi.EnvParams * n)(*[e._c() for e in envs])
+        prof_arr = (_capi.Profile * n)(*[e.country_profile._c() for e in envs])
+        seeds = i32([e.seed for e in envs])
+        d = _capi.WorldDesc()
+        d.n, d.batch, d.pop = n, batch, ptr(pops, C.c_int32)
+        d.conn = ptr(dense, C.c_double) if dense is not None else None
+        d.csr_rowptr = ptr(rp, C.c_int32) if rp is not None else None
+        d.csr_col = ptr(col, C.c_int32) if col is not None else None
+        d.csr_val = ptr(val, C.c_double) if val is not None else None
+        d.seed_idx, d.validate, d.base = seed_idx, int(validate), base._c()
+        d.env, d.prof, d.env_seeds, d.hp, d.device = env_arr, prof_arr, ptr(seeds, C.c_int32), hp._c(), device
+        h = lib().epi_world_create(C.byref(d))
+        if not h:
+            msg = _capi.last_error()
+            if "requirement failed" in msg:
+                raise IllegalArgumentException(_capi.EPI_ERR_ASSERT_STATE, msg)
+            raise EpiError(_capi.EPI_ERR_BAD_ARGUMENT, msg)
+        self._h = C.c_void_p(h)
+        self._agents = [_AgentStream(hp) for _ in range(n)]
+        self._mlp = None
+        st0 = self._get_states()
+        self.nodes = [WorldToy.Node(i, c.name, c.pop, envs[i], hp, st0[0][i]) for i, c in enumerate(self.countries)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().epi_world_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state access -------------------------------------------------------------------------
+    def _get_states(self) -> List[List[State]]:
+        arr = (_capi.CState * (self.batch * self.n))()
+        check(lib().epi_world_get_states(self._h, arr))
+        return [[State._from_c(arr[b * self.n + c]) for c in range(self.n)] for b in range(self.batch)]
+
+    def snapshot_states(self) -> List[State]:  # WorldToy.scala:75
+        return self._get_states()[0] if self.batch == 1 else self._get_states()
+
+    def restore_states(self, ss) -> None:  # :76
+        flat = ss if self.batch == 1 else [s for inst in ss for s in inst]
+        arr = (_capi.CState * (self.batch * self.n))(*[s._c() for s in flat])
+        check(lib().epi_world_set_states(self._h, arr))
+        self._sync_nodes()
+
+    def reset_to_initial(self) -> None:  # :77
+        check(lib().epi_world_reset(self._h))
+        self._sync_nodes()
+
+    def _sync_nodes(self):
+        st = self._get_states()[0]
+        for node, s in zip(self.nodes, st):
+            node.s = s
+
+    def last_flows(self):
+        ms = np.zeros((self.batch, self.n), dtype=np.int32); mi = np.zeros((self.batch, self.n), dtype=np.int32)
+        check(lib().epi_world_last_flows(self._h, ptr(ms, C.c_int32), ptr(mi, C.c_int32)))
+        return ms, mi
+
+    # -- stepping -----------------------------------------------------------------------------
+    def step_actions(self, actions, gauss=None, t_max: Optional[int] = None):
+        """One stepOne with caller-chosen actions[batch][n]; returns (states, rewards) arrays."""
+        a = i32(np.asarray(actions).reshape(self.batch, self.n))
+        g = None if gauss is None else f64(np.asarray(gauss).reshape(self.batch, self.n))
+        out = (_capi.CState * (self.batch * self.n))()
+        r = np.zeros((self.batch, self.n))
+        check(lib().epi_world_step(self._h, ptr(a, C.c_int32), ptr(g, C.c_double) if g is not None else None,
+                                   C.c_int32(self.base.t_max if t_max is None else t_max), out, ptr(r, C.c_double)))
+        states = [[State._from_c(out[b * self.n + c]) for c in range(self.n)] for b in range(self.batch)]
+        for node, s, act in zip(self.nodes, states[0], a[0]):
+            node.s, node.last_a = s, int(act)
+        return states, r
+
+    def set_mlp(self, W1, W2, W3, b1=None, b2=None, b3=None, clip_q=None):
+        W1, W2, W3 = f64(W1), f64(W2), f64(W3)
+        bs = [None if b is None else f64(b) for b in (b1, b2, b3)]
+        check(lib().epi_world_set_mlp(self._h, C.c_int32(W1.shape[0]), ptr(W1, C.c_double),
+                                      ptr(bs[0], C.c_double) if bs[0] is not None else None, ptr(W2, C.c_double),
+                                      ptr(bs[1], C.c_double) if bs[1] is not None else None, ptr(W3, C.c_double),
+                                      ptr(bs[2], C.c_double) if bs[2] is not None else None,
+                                      C.c_double(self.hp.clip_q if clip_q is None else clip_q)))
+        self._mlp = (W1, W2, W3)
+
+    def _ensure_untrained_mlp(self):
+        if self._mlp is None:
+            self.set_mlp(*mlp_init(self.hp.hidden))
+
+    def step_one(self, t_max: int) -> List[Tuple[str, State, float]]:
+        """WorldToy.stepOne (:83-170) with never-trained agents: the epsilon-greedy draws follow the
+        JVM streams; the DDQN update itself stays with the trainer and is not part of this engine."""
+        assert self.batch == 1, "step_one mirrors the single-world API; use step_actions for batches"
+        acts = [ag.next() for ag in self._agents]
+        if any(a < 0 for a in acts):
+            self._ensure_untrained_mlp()
+            _, greedy = mlp_greedy([nd.s for nd in self.nodes], self._mlp, self.hp.clip_q)
+            acts = [int(g) if a < 0 else a for a, g in zip(acts, greedy)]
+        states, r = self.step_actions([acts], None, t_max)
+        return [(nd.name, s, float(rv)) for nd, s, rv in zip(self.nodes, states[0], r[0])]
+
+    def step_one_greedy(self, t_max: int) -> List[Tuple[str, State, float]]:  # :172-235
+        self._ensure_untrained_mlp()
+        out = (_capi.CState * (self.batch * self.n))()
+        r = np.zeros((self.batch, self.n)); a = np.zeros((self.batch, self.n), dtype=np.int32)
+        check(lib().epi_world_step_greedy(self._h, None, C.c_int32(t_max), out, ptr(r, C.c_double), ptr(a, C.c_int32)))
+        states = [State._from_c(out[c]) for c in range(self.n)]
+        for node, s, act in zip(self.nodes, states, a[0]):
+            node.s, node.last_a = s, int(act)
+        return [(nd.name, s, float(rv)) for nd, s, rv in zip(self.nodes, states, r[0])]
+
+
+# ------------------------------------------------------------------------------------------------
+# Calibrate.scala
+# ------------------------------------------------------------------------------------------------
+class GridEngine:
+    """Device-resident calibration sweep (epi_grid_*): build once, run slabs of grid points."""
+
+    def __init__(self, hp: HyperParams, steps: int, base: State, seed_idx: int, pops, conn, profiles, betas, travel,
+                 t_arrive=None, t_peak=None, heterogeneous=True, device: int = 0):
+        self.n = len(pops)
+        self.betas, self.travel = f64(betas), f64(travel)
+        self.G = len(self.betas) * len(self.travel)
+        pops = i32(pops)
+        dense, rp, col, val = _csr_or_dense(conn)
+        prof_arr = (_capi.Profile * self.n)(*[p._c() if hasattr(p, "_c") else _capi.Profile(*p) for p in profiles])
+        ta = np.zeros(self.n); tp = np.zeros(self.n)
+        ha = np.zeros(self.n, dtype=np.uint8); hk = np.zeros(self.n, dtype=np.uint8)
+        for c, v in (t_arrive or {}).items():
+            ta[c], ha[c] = v, 1
+        for c, v in (t_peak or {}).items():
+            tp[c], hk[c] = v, 1
+        d = _capi.GridDesc()
+        d.n, d.pop = self.n, ptr(pops, C.c_int32)
+        d.conn = ptr(dense, C.c_double) if dense is not None else None
+        d.csr_rowptr = ptr(rp, C.c_int32) if rp is not None else None
+        d.csr_col = ptr(col, C.c_int32) if col is not None else None
+        d.csr_val = ptr(val, C.c_double) if val is not None else None
+        d.seed_idx, d.heterogeneous, d.base, d.prof, d.hp, d.steps = seed_idx, int(heterogeneous), base._c(), prof_arr, hp._c(), steps
+        d.n_beta, d.betas, d.n_travel, d.travel = len(self.betas), ptr(self.betas, C.c_double), len(self.travel), ptr(self.travel, C.c_double)
+        d.t_arrive, d.has_arrive, d.t_peak, d.has_peak = ptr(ta, C.c_double), ptr(ha, C.c_uint8), ptr(tp, C.c_double), ptr(hk, C.c_uint8)
+        d.device = device
+        h = lib().epi_grid_create(C.byref(d))
+        if not h:
+            msg = _capi.last_error()
+            if "requirement failed" in msg:
+                raise IllegalArgumentException(_capi.EPI_ERR_ASSERT_STATE, msg)
+            raise EpiError(_capi.EPI_ERR_DEVICE if "HIP" in msg or "hip" in msg else _capi.EPI_ERR_BAD_ARGUMENT, msg)
+        self._h = C.c_void_p(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().epi_grid_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, g_begin: int = 0, g_count: Optional[int] = None, want_metrics: bool = True):
+        """Synchronous run of a slab; returns dict(loss, arrival, peak) as host arrays."""
+        g_count = self.G - g_begin if g_count is None else g_count
+        loss = np.zeros(g_count)
+        arr = np.zeros((g_count, self.n), dtype=np.int32) if want_metrics else None
+        pk = np.zeros((g_count, self.n)) if want_metrics else None
+        check(lib().epi_grid_run(self._h, g_begin, g_count, loss.ctypes.data, arr.ctypes.data if want_metrics else None,
+                                 pk.ctypes.data if want_metrics else None, 0, None))
+        return dict(loss=loss, arrival=arr, peak=pk)
+
+    def enqueue(self, g_begin: int, g_count: int, loss_dev_ptr: int, stream: int = 0, arrival_dev_ptr: int = 0,
+                peak_dev_ptr: int = 0):
+        """Asynchronous run into device buffers (raw addresses) on `stream` (a hipStream_t address)."""
+        check(lib().epi_grid_run(self._h, g_begin, g_count, loss_dev_ptr or None, arrival_dev_ptr or None,
+                                 peak_dev_ptr or None, 1, stream or None))
+
+    def status(self):
+        check(lib().epi_grid_status(self._h))
+
+
+def grid_argmin(loss) -> Tuple[int, float]:
+    loss = f64(loss)
+    bi = C.c_int32(0); bl = C.c_double(0)
+    check(lib().epi_grid_argmin(ptr(loss, C.c_double), C.c_int32(len(loss)), C.byref(bi), C.byref(bl)))
+    return bi.value, bl.value
+
+
+class Calibrate:
+    @dataclass
+    class Targets:  # Calibrate.scala:8-12
+        t_arrive: Dict[str, float] = field(default_factory=dict)
+        peak_i: Dict[str, float] = field(default_factory=dict)
+        thresh_i: float = 10.0
+
+    @staticmethod
+    def grid_surface(hp: HyperParams, cfg: TrainConfig, base: State, seed_idx: int, targets: "Calibrate.Targets",
+                     beta_grid: Sequence[float], travel_scales: Sequence[float], validate: bool = True,
+                     heterogeneous: bool = True, countries: Optional[Sequence[Geo.Country]] = None, conn=None,
+                     device: int = 0):
+        """Calibrate.gridSurface (:84-116): (rows [(beta, ts, loss)], (bestLoss, (beta, ts)))."""
+        countries = list(countries) if countries is not None else list(ToyConn.C)
+        conn = ToyConn.W if conn is None else conn
+        names = [c.name for c in countries]
+        profiles = [Geo.CountryProfiles.get_profile(c.name) if c.name in Geo.CountryProfiles._TABLE else c
+                    for c in countries]
+        ta = {names.index(k): v for k, v in targets.t_arrive.items() if k in names}
+        tp = {names.index(k): v for k, v in targets.peak_i.items() if k in names}
+        if len(beta_grid) == 0 or len(travel_scales) == 0:
+            best = (beta_grid[0] if len(beta_grid) else 0.25, travel_scales[0] if len(travel_scales) else 1.0)
+            return [], (1.7976931348623157e308, best)
+        eng = GridEngine(hp, cfg.steps_per_epoch, base, seed_idx, [c.pop for c in countries], conn, profiles,
+                         beta_grid, travel_scales, ta, tp, heterogeneous, device)
+        try:
+            out = eng.run(0, None, want_metrics=False)
+        finally:
+            eng.close()
+        loss = out["loss"]
+        rows = [(float(b), float(ts), float(loss[i * len(travel_scales) + k]))
+                for i, b in enumerate(beta_grid) for k, ts in enumerate(travel_scales)]
+        bi, bl = grid_argmin(loss)
+        return rows, (bl, (rows[bi][0], rows[bi][1]))

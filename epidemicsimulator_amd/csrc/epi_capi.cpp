@@ -1,0 +1,979 @@
+// Host engine and C ABI (include/epi.h).  Builds the per-sweep tables with the reference's
+// operation order (compiled with -ffp-contract=off), owns the device buffers and enqueues the
+// kernels of epi_kernels.hip.  There is no CPU compute path: every entry point that computes
+// needs a HIP device and fails with EPI_ERR_DEVICE without one.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/epi.h"
+#include "epi_kernels.hpp"
+#include "java_compat.hpp"
+
+#define EPI_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+using namespace epi;
+
+thread_local std::string g_last_error;
+thread_local int32_t g_last_code = 0;
+
+int32_t fail(int32_t code, const char* fmt, ...) {
+    g_last_code = code;
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(EPI_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int32_t use_device(int device) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(EPI_ERR_DEVICE, "no HIP device available: the engine has no CPU fallback");
+    if (device < 0 || device >= count) return fail(EPI_ERR_BAD_ARGUMENT, "device %d out of range [0,%d)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    return EPI_OK;
+}
+
+// Owning device allocation.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t ensure(size_t want) {
+        if (want <= bytes && p) return hipSuccess;
+        release();
+        if (want == 0) want = 16;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    template <class T>
+    hipError_t upload(const std::vector<T>& v) {
+        hipError_t e = ensure(v.size() * sizeof(T));
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    template <class T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
+const epi_profile kDefaultProfile = {1.0, 1.0, 0.05, 100.0, 30000.0, 0.7, 0.15, 0.8, 0.7};  // Geo.scala:4-21
+
+Hyper to_hyper(const epi_hyper& h) {
+    Hyper o;
+    o.epsilon_start = h.epsilon_start; o.epsilon_end = h.epsilon_end;
+    o.epsilon_decay_steps = h.epsilon_decay_steps; o.hidden = h.hidden;
+    o.clip_q = h.clip_q; o.reward_clip = h.reward_clip; o.batch_size = h.batch_size; o.learn_every = h.learn_every;
+    return o;
+}
+
+bool is_count(double x) { return std::isfinite(x) && x >= 0.0 && x <= 2147483647.0 && std::floor(x) == x; }
+
+// ToyConn.scaleRow on one row (ToyConn.scala:58-70).
+void scale_row_inplace(double* row, int n, int self, double factor) {
+    double s = 0.0;
+    for (int j = 0; j < n; ++j)
+        if (j != self) { row[j] *= factor; s += row[j]; }
+    const double cap = std::fmin(0.2, s);
+    if (s > cap && s > 0) {
+        const double sc = cap / s;
+        for (int j = 0; j < n; ++j)
+            if (j != self) row[j] *= sc;
+    }
+    row[self] = 0.0;
+}
+
+// Normalised row for the mobility split: wRow_j = (j == i) ? 0 : W_ij, sumW = wRow.sum
+// (left to right), export factor max(0, sumW) (WorldToy.scala:113-114) and q_j = wRow_j / sumW,
+// the first of allocateInt's two roundings (env.scala:244).  A non-positive sum makes allocateInt
+// return zeros (env.scala:243): q is left at 0.
+int32_t normalise_row(const double* wrow_in, int n, int self, double* q_out, double* sumw_out) {
+    double sum = 0.0;
+    for (int j = 0; j < n; ++j) {
+        const double w = (j == self) ? 0.0 : wrow_in[j];
+        if (!std::isfinite(w) || w < 0.0)
+            return fail(EPI_ERR_BAD_ARGUMENT, "connection weight (%d,%d) = %g: weights must be finite and >= 0", self, j, w);
+        sum = (j == 0) ? w : sum + w;
+    }
+    *sumw_out = std::fmax(0.0, sum);
+    for (int j = 0; j < n; ++j) {
+        const double w = (j == self) ? 0.0 : wrow_in[j];
+        q_out[j] = (sum > 0.0) ? w / sum : 0.0;
+    }
+    return EPI_OK;
+}
+
+// Dense row-major copy of the connection matrix from either input form.
+int32_t densify(int n, const double* conn, const int32_t* rowptr, const int32_t* col, const double* val,
+                std::vector<double>& W) {
+    W.assign((size_t)n * n, 0.0);
+    if (conn) {
+        std::memcpy(W.data(), conn, sizeof(double) * (size_t)n * n);
+        return EPI_OK;
+    }
+    if (!rowptr || !col || !val) return fail(EPI_ERR_BAD_ARGUMENT, "neither a dense matrix nor a CSR triple was given");
+    for (int i = 0; i < n; ++i) {
+        int prev = -1;
+        for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            const int j = col[k];
+            if (j < 0 || j >= n || j <= prev)
+                return fail(EPI_ERR_BAD_ARGUMENT, "CSR row %d: column indices must be ascending and in [0,n)", i);
+            prev = j;
+            W[(size_t)i * n + j] = val[k];
+        }
+    }
+    return EPI_OK;
+}
+
+// Device-resident tables shared by the sweep and the world API.
+struct GraphTables {
+    int n = 0, npad = 0;
+    DevBuf q, sumw, pop;
+    std::vector<double> W;  // dense host copy (seed-row variants are derived from it)
+    int32_t build(int n_, const int32_t* pop_, const double* conn, const int32_t* rowptr, const int32_t* col,
+                  const double* val) {
+        n = n_;
+        npad = dense_slots_for(n) * 64;
+        int32_t rc = densify(n, conn, rowptr, col, val, W);
+        if (rc) return rc;
+        std::vector<double> hq((size_t)n * npad, 0.0), hs((size_t)npad, 0.0);
+        for (int i = 0; i < n; ++i) {
+            rc = normalise_row(&W[(size_t)i * n], n, i, &hq[(size_t)i * npad], &hs[i]);
+            if (rc) return rc;
+        }
+        std::vector<int32_t> hp((size_t)npad, 0);
+        for (int c = 0; c < n; ++c) {
+            if (pop_[c] < 0) return fail(EPI_ERR_BAD_ARGUMENT, "pop[%d] = %d is negative", c, pop_[c]);
+            hp[c] = pop_[c];
+        }
+        HIP_TRY(q.upload(hq));
+        HIP_TRY(sumw.upload(hs));
+        HIP_TRY(pop.upload(hp));
+        return EPI_OK;
+    }
+};
+
+// Per-episode work buffers.
+struct EpisodeBuffers {
+    int count = 0, npad = 0;
+    DevBuf st, cap, tcur, arrival, peak, err, act_ep;
+    int32_t ensure(int count_, int npad_) {
+        if (count_ <= count && npad_ == npad) return EPI_OK;
+        const size_t cells = (size_t)count_ * npad_;
+        HIP_TRY(st.ensure(cells * 5 * sizeof(int32_t)));
+        HIP_TRY(cap.ensure(cells * sizeof(double)));
+        HIP_TRY(tcur.ensure(cells * sizeof(int32_t)));
+        HIP_TRY(arrival.ensure(cells * sizeof(int32_t)));
+        HIP_TRY(peak.ensure(cells * sizeof(int32_t)));
+        HIP_TRY(err.ensure((size_t)count_ * 4 * sizeof(int32_t)));
+        HIP_TRY(act_ep.ensure(cells));
+        count = count_;
+        npad = npad_;
+        return EPI_OK;
+    }
+};
+
+struct MlpDevice {
+    int hidden = 0;
+    double clip_q = 10.0;
+    DevBuf W1, b1, W2T, b2, W3, b3;
+    bool has_bias = false;
+    int32_t upload(int h, const double* w1, const double* bb1, const double* w2, const double* bb2, const double* w3,
+                   const double* bb3, double clip) {
+        if (h < 1 || h > 128) return fail(EPI_ERR_BAD_ARGUMENT, "hidden = %d: the device network supports 1..128 units", h);
+        hidden = h;
+        clip_q = clip;
+        std::vector<double> t((size_t)h * h);
+        for (int u = 0; u < h; ++u)
+            for (int k = 0; k < h; ++k) t[(size_t)k * h + u] = w2[(size_t)u * h + k];
+        HIP_TRY(W1.upload(std::vector<double>(w1, w1 + (size_t)h * 7)));
+        HIP_TRY(W2T.upload(t));
+        HIP_TRY(W3.upload(std::vector<double>(w3, w3 + (size_t)8 * h)));
+        std::vector<double> z1((size_t)h, 0.0), z3(8, 0.0);
+        HIP_TRY(b1.upload(bb1 ? std::vector<double>(bb1, bb1 + h) : z1));
+        HIP_TRY(b2.upload(bb2 ? std::vector<double>(bb2, bb2 + h) : z1));
+        HIP_TRY(b3.upload(bb3 ? std::vector<double>(bb3, bb3 + 8) : z3));
+        return EPI_OK;
+    }
+    void fill(MlpArgs& a) const {
+        a.hidden = hidden;
+        a.W1 = W1.as<double>(); a.b1 = b1.as<double>();
+        a.W2T = W2T.as<double>(); a.b2 = b2.as<double>();
+        a.W3 = W3.as<double>(); a.b3 = b3.as<double>();
+        a.clip_q = clip_q;
+    }
+};
+
+const char* status_text(int code) {
+    switch (code) {
+        case EPI_ERR_LOCAL_MASS: return "requirement failed: mass not conserved (local)";
+        case EPI_ERR_WORLD_MASS: return "requirement failed: global mass changed during mobility";
+        case EPI_ERR_INT_RANGE: return "a compartment left the 32-bit Int range the reference computes in";
+        default: return "device-side failure";
+    }
+}
+
+// First failing episode of a run, from the device error table.
+int32_t collect_errors(const DevBuf& err, int count, int g_begin) {
+    std::vector<int32_t> h((size_t)count * 4);
+    HIP_TRY(hipMemcpy(h.data(), err.p, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int e = 0; e < count; ++e)
+        if (h[(size_t)e * 4] != 0)
+            return fail(h[(size_t)e * 4], "%s (instance %d, country %d, t=%d)", status_text(h[(size_t)e * 4]), g_begin + e,
+                        h[(size_t)e * 4 + 1], h[(size_t)e * 4 + 2]);
+    return EPI_OK;
+}
+
+int32_t check_base_state(const epi_state& b, const char* who) {
+    if (!is_count(b.r) || !is_count(b.d) || !is_count(b.v))
+        return fail(EPI_ERR_BAD_ARGUMENT, "%s: base r/d/v must be non-negative integers below 2^31", who);
+    if (!std::isfinite(b.hosp_cap)) return fail(EPI_ERR_BAD_ARGUMENT, "%s: base hospCap must be finite", who);
+    return EPI_OK;
+}
+
+// Validation.assertState on the initial states (WorldToy.scala:53): s, i >= 0 by construction;
+// round(total) must equal pop, i.e. r + d + v must be 0; 0 <= t <= tMax.
+int32_t assert_initial(const epi_state& b) {
+    if (b.r + b.d + b.v != 0.0)
+        return fail(EPI_ERR_ASSERT_STATE, "requirement failed: mass not conserved: initial r+d+v = %g must be 0", b.r + b.d + b.v);
+    if (!(b.t >= 0 && b.t <= b.t_max))
+        return fail(EPI_ERR_ASSERT_STATE, "requirement failed: t out of bounds: %d not in [0, %d]", b.t, b.t_max);
+    return EPI_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// handles
+// ================================================================================================
+struct epi_grid {
+    int device = 0;
+    int n = 0, npad = 0, steps = 0, n_beta = 0, n_travel = 0, seed_idx = 0;
+    epi_state base{};
+    GraphTables graph;
+    DevBuf qseed, sumw_seed, beta0, cst, actions, noise;
+    DevBuf t_arrive, has_arrive, t_peak, has_peak;
+    MlpDevice mlp;
+    std::vector<int> greedy_steps;
+    EpisodeBuffers work;
+    DevBuf loss_tmp, arrival_tmp, peak_tmp;
+    int last_count = 0, last_g_begin = 0;
+    bool pending = false;
+};
+
+struct epi_world {
+    int device = 0;
+    int n = 0, npad = 0, batch = 0, seed_idx = 0, validate = 0;
+    epi_state base{};
+    GraphTables graph;
+    DevBuf beta0, cst, rwd;
+    MlpDevice mlp;
+    bool mlp_set = false;
+    EpisodeBuffers work;
+    DevBuf act_dev, gauss_dev, reward_dev, flow_s, flow_i, q_tmp;
+    std::vector<JavaRandom> env_rnd;  // one stream per country (env.scala:42)
+    std::vector<int32_t> env_seeds;
+    bool have_flows = false;
+};
+
+// ================================================================================================
+// basics
+// ================================================================================================
+EPI_API int32_t epi_version(void) { return 100; }
+
+EPI_API int32_t epi_last_error(char* buf, size_t cap) {
+    if (buf && cap > 0) {
+        const size_t k = g_last_error.size() < cap - 1 ? g_last_error.size() : cap - 1;
+        std::memcpy(buf, g_last_error.data(), k);
+        buf[k] = 0;
+    }
+    return (int32_t)g_last_error.size();
+}
+
+EPI_API int32_t epi_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+// ================================================================================================
+// host-side JVM-compatible streams
+// ================================================================================================
+EPI_API int32_t epi_java_gaussians(int64_t seed, int32_t n, double* out) {
+    if (n < 0 || (n > 0 && !out)) return fail(EPI_ERR_BAD_ARGUMENT, "epi_java_gaussians: bad arguments");
+    JavaRandom r(seed);
+    for (int k = 0; k < n; ++k) out[k] = r.nextGaussian();
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_agent_actions(const epi_hyper* hp, int32_t steps, int32_t* out) {
+    if (!hp || steps < 0 || (steps > 0 && !out)) return fail(EPI_ERR_BAD_ARGUMENT, "epi_agent_actions: bad arguments");
+    AgentStream ag;
+    const Hyper h = to_hyper(*hp);
+    for (int t = 0; t < steps; ++t) out[t] = ag.act(h);
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_mlp_init(int32_t n_in, int32_t hidden, int32_t n_out, double* W1, double* W2, double* W3) {
+    if (n_in < 1 || hidden < 1 || n_out < 1 || !W1 || !W2 || !W3) return fail(EPI_ERR_BAD_ARGUMENT, "epi_mlp_init: bad arguments");
+    std::vector<double> a, b, c;
+    mlp_init(n_in, hidden, n_out, a, b, c);
+    std::memcpy(W1, a.data(), a.size() * sizeof(double));
+    std::memcpy(W2, b.data(), b.size() * sizeof(double));
+    std::memcpy(W3, c.data(), c.size() * sizeof(double));
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_scale_row(const double* W, int32_t n, int32_t row, double factor, double* out) {
+    if (!W || !out || n < 1 || row < 0 || row >= n) return fail(EPI_ERR_BAD_ARGUMENT, "epi_scale_row: bad arguments");
+    if (out != W) std::memcpy(out, W, sizeof(double) * (size_t)n * n);
+    scale_row_inplace(out + (size_t)row * n, n, row, factor);
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_grid_argmin(const double* loss, int32_t count, int32_t* best_idx, double* best_loss) {
+    if (count < 0 || (count > 0 && !loss)) return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_argmin: bad arguments");
+    double bl = std::numeric_limits<double>::max();  // Calibrate.scala:96
+    int32_t bi = 0;
+    for (int g = 0; g < count; ++g)
+        if (loss[g] < bl) { bl = loss[g]; bi = g; }  // :112
+    if (best_idx) *best_idx = bi;
+    if (best_loss) *best_loss = bl;
+    return EPI_OK;
+}
+
+// ================================================================================================
+// batched unit operations
+// ================================================================================================
+EPI_API int32_t epi_alloc_int_batch(const int32_t* totals, const double* w, int32_t n, int32_t batch, int32_t* out) {
+    if (n < 0 || batch < 0) return fail(EPI_ERR_BAD_ARGUMENT, "epi_alloc_int_batch: negative size");
+    if (n == 0 || batch == 0) return EPI_OK;
+    if (!totals || !w || !out) return fail(EPI_ERR_BAD_ARGUMENT, "epi_alloc_int_batch: null pointer");
+    if (n > kMaxDenseN) return fail(EPI_ERR_BAD_ARGUMENT, "epi_alloc_int_batch: n = %d exceeds the %d weights one wave holds", n, kMaxDenseN);
+    const size_t cells = (size_t)n * batch;
+    for (size_t k = 0; k < cells; ++k)
+        if (!std::isfinite(w[k]) || w[k] < 0.0) return fail(EPI_ERR_BAD_ARGUMENT, "epi_alloc_int_batch: weight %zu = %g must be finite and >= 0", k, w[k]);
+    int32_t rc = use_device(0);
+    if (rc) return rc;
+    DevBuf dt, dw, dout;
+    HIP_TRY(dt.ensure(sizeof(int32_t) * (size_t)batch));
+    HIP_TRY(dw.ensure(sizeof(double) * cells));
+    HIP_TRY(dout.ensure(sizeof(int32_t) * cells));
+    HIP_TRY(hipMemcpy(dt.p, totals, sizeof(int32_t) * (size_t)batch, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dw.p, w, sizeof(double) * cells, hipMemcpyHostToDevice));
+    AllocBatchArgs a{n, dense_slots_for(n) * 64, batch, dt.as<int32_t>(), dw.as<double>(), dout.as<int32_t>()};
+    HIP_TRY(launch_alloc_batch(a, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, sizeof(int32_t) * cells, hipMemcpyDeviceToHost));
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_alloc_int(int32_t total, const double* w, int32_t n, int32_t* out) {
+    return epi_alloc_int_batch(&total, w, n, 1, out);
+}
+
+EPI_API int32_t epi_env_step_batch(const epi_env_params* env, const epi_profile* prof, const epi_state* in,
+                                   const int32_t* action, const double* gauss, epi_state* out, double* reward,
+                                   uint8_t* done, int32_t batch) {
+    if (batch < 0) return fail(EPI_ERR_BAD_ARGUMENT, "epi_env_step_batch: negative batch");
+    if (batch == 0) return EPI_OK;
+    if (!env || !prof || !in || !action || !gauss || !out) return fail(EPI_ERR_BAD_ARGUMENT, "epi_env_step_batch: null pointer");
+    for (int b = 0; b < batch; ++b) {
+        const epi_state& s = in[b];
+        if (!std::isfinite(s.s) || !std::isfinite(s.i) || !std::isfinite(s.r) || !std::isfinite(s.d) || !std::isfinite(s.v) ||
+            !std::isfinite(s.hosp_cap) || !std::isfinite(gauss[b]))
+            return fail(EPI_ERR_BAD_ARGUMENT, "epi_env_step_batch: row %d holds a non-finite value", b);
+    }
+    int32_t rc = use_device(0);
+    if (rc) return rc;
+    DevBuf de, dp, di, da, dg, dout, dr, dd;
+    const size_t B = (size_t)batch;
+    HIP_TRY(de.ensure(B * sizeof(epi_env_params)));
+    HIP_TRY(dp.ensure(B * sizeof(epi_profile)));
+    HIP_TRY(di.ensure(B * sizeof(epi_state)));
+    HIP_TRY(da.ensure(B * sizeof(int32_t)));
+    HIP_TRY(dg.ensure(B * sizeof(double)));
+    HIP_TRY(dout.ensure(B * sizeof(epi_state)));
+    HIP_TRY(dr.ensure(B * sizeof(double)));
+    HIP_TRY(dd.ensure(B));
+    HIP_TRY(hipMemcpy(de.p, env, B * sizeof(epi_env_params), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dp.p, prof, B * sizeof(epi_profile), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(di.p, in, B * sizeof(epi_state), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(da.p, action, B * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dg.p, gauss, B * sizeof(double), hipMemcpyHostToDevice));
+    EnvBatchArgs a{batch, de.as<epi_env_params>(), dp.as<epi_profile>(), di.as<epi_state>(), da.as<int32_t>(),
+                   dg.as<double>(), dout.as<epi_state>(), dr.as<double>(), dd.as<uint8_t>()};
+    HIP_TRY(launch_env_batch(a, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, B * sizeof(epi_state), hipMemcpyDeviceToHost));
+    if (reward) HIP_TRY(hipMemcpy(reward, dr.p, B * sizeof(double), hipMemcpyDeviceToHost));
+    if (done) HIP_TRY(hipMemcpy(done, dd.p, B, hipMemcpyDeviceToHost));
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_mlp_greedy_batch(const epi_state* states, int32_t batch, int32_t hidden, const double* W1,
+                                     const double* b1, const double* W2, const double* b2, const double* W3,
+                                     const double* b3, double clip_q, double* q, int32_t* action) {
+    if (batch < 0) return fail(EPI_ERR_BAD_ARGUMENT, "epi_mlp_greedy_batch: negative batch");
+    if (batch == 0) return EPI_OK;
+    if (!states || !W1 || !W2 || !W3) return fail(EPI_ERR_BAD_ARGUMENT, "epi_mlp_greedy_batch: null pointer");
+    int32_t rc = use_device(0);
+    if (rc) return rc;
+    MlpDevice m;
+    rc = m.upload(hidden, W1, b1, W2, b2, W3, b3, clip_q);
+    if (rc) return rc;
+    DevBuf ds, dq, da;
+    HIP_TRY(ds.ensure((size_t)batch * sizeof(epi_state)));
+    HIP_TRY(dq.ensure((size_t)batch * 8 * sizeof(double)));
+    HIP_TRY(da.ensure((size_t)batch * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(ds.p, states, (size_t)batch * sizeof(epi_state), hipMemcpyHostToDevice));
+    MlpArgs a{};
+    a.rows = batch; a.n = 1; a.npad = 1;
+    a.states = ds.as<epi_state>();
+    m.fill(a);
+    a.act_out = da.as<int32_t>();
+    a.q_out = dq.as<double>();
+    HIP_TRY(launch_mlp(a, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    if (q) HIP_TRY(hipMemcpy(q, dq.p, (size_t)batch * 8 * sizeof(double), hipMemcpyDeviceToHost));
+    if (action) HIP_TRY(hipMemcpy(action, da.p, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return EPI_OK;
+}
+
+// ================================================================================================
+// calibration sweep
+// ================================================================================================
+static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
+    if (d->n < 1) return fail(EPI_ERR_BAD_ARGUMENT, "grid: n = %d", d->n);
+    if (d->n > kMaxDenseN)
+        return fail(EPI_ERR_BAD_ARGUMENT, "grid: n = %d countries exceeds the %d the register-resident row kernel holds", d->n, kMaxDenseN);
+    if (!d->pop || d->seed_idx < 0 || d->seed_idx >= d->n || d->steps < 0 || d->n_beta < 0 || d->n_travel < 0)
+        return fail(EPI_ERR_BAD_ARGUMENT, "grid: bad sizes or null pop");
+    if ((d->n_beta > 0 && !d->betas) || (d->n_travel > 0 && !d->travel)) return fail(EPI_ERR_BAD_ARGUMENT, "grid: null grid axis");
+    if (d->heterogeneous && !d->prof) return fail(EPI_ERR_BAD_ARGUMENT, "grid: heterogeneous sweep needs country profiles");
+    int32_t rc = check_base_state(d->base, "grid");
+    if (rc) return rc;
+    rc = assert_initial(d->base);  // validate = true is hard-wired in Calibrate.rollout (Calibrate.scala:64)
+    if (rc) return rc;
+    rc = use_device(d->device);
+    if (rc) return rc;
+    G->device = d->device;
+    G->n = d->n; G->steps = d->steps; G->n_beta = d->n_beta; G->n_travel = d->n_travel; G->seed_idx = d->seed_idx;
+    G->base = d->base;
+    rc = G->graph.build(d->n, d->pop, d->conn, d->csr_rowptr, d->csr_col, d->csr_val);
+    if (rc) return rc;
+    const int n = d->n, npad = G->graph.npad;
+    G->npad = npad;
+
+    // seed-row variants: ToyConn.scaleRow(W, seedIdx, ts) touches only that row (Calibrate.scala:29)
+    {
+        std::vector<double> hq((size_t)(d->n_travel > 0 ? d->n_travel : 1) * npad, 0.0), hs((size_t)(d->n_travel > 0 ? d->n_travel : 1), 0.0);
+        std::vector<double> row((size_t)n);
+        for (int k = 0; k < d->n_travel; ++k) {
+            if (!std::isfinite(d->travel[k]) || d->travel[k] < 0.0) return fail(EPI_ERR_BAD_ARGUMENT, "grid: travel scale %d = %g", k, d->travel[k]);
+            std::memcpy(row.data(), &G->graph.W[(size_t)d->seed_idx * n], sizeof(double) * (size_t)n);
+            scale_row_inplace(row.data(), n, d->seed_idx, d->travel[k]);
+            rc = normalise_row(row.data(), n, d->seed_idx, &hq[(size_t)k * npad], &hs[k]);
+            if (rc) return rc;
+        }
+        HIP_TRY(G->qseed.upload(hq));
+        HIP_TRY(G->sumw_seed.upload(hs));
+    }
+    // per-country environments (Calibrate.scala:31-51)
+    const Hyper hp = to_hyper(d->hp);
+    {
+        const int nb = d->n_beta > 0 ? d->n_beta : 1;
+        std::vector<double> hb((size_t)nb * npad, 0.0), hc((size_t)CST_COUNT * npad, 0.0);
+        for (int c = 0; c < n; ++c) {
+            const epi_profile& p = d->heterogeneous ? d->prof[c] : kDefaultProfile;
+            epi_env_params e;
+            e.base_gamma = 0.12;
+            e.base_ifr = d->heterogeneous ? 0.008 * (1.0 + p.age_elderly * 2.0) : 0.008;
+            e.noise = d->heterogeneous ? 0.05 * (1.0 + (1.0 - p.econ_resilience)) : 0.05;
+            e.reward_clip = hp.reward_clip;
+            e.risk_factor = 0.0;
+            for (int b = 0; b < d->n_beta; ++b) {
+                const double beta = d->betas[b];
+                if (!std::isfinite(beta)) return fail(EPI_ERR_BAD_ARGUMENT, "grid: beta %d is not finite", b);
+                e.base_beta = d->heterogeneous
+                                  ? beta * (1.0 + (p.population_density / 1000.0) * 0.5) * (3.0 - p.healthcare_capacity * 2.0)
+                                  : beta;
+                hb[(size_t)b * npad + c] = make_step_consts(e, p).beta0;
+            }
+            e.base_beta = 0.0;
+            const StepConsts sc = make_step_consts(e, p);
+            hc[(size_t)CST_GAMMA * npad + c] = sc.gamma;
+            hc[(size_t)CST_IFR0 * npad + c] = sc.ifr0;
+            hc[(size_t)CST_CNOISE * npad + c] = sc.cnoise;
+            hc[(size_t)CST_EFF1 * npad + c] = sc.eff1;
+            hc[(size_t)CST_EFF2 * npad + c] = sc.eff2;
+            hc[(size_t)CST_EFF3 * npad + c] = sc.eff3;
+            hc[(size_t)CST_SURGE * npad + c] = sc.surge;
+            hc[(size_t)CST_VAX6 * npad + c] = sc.vax6;
+            hc[(size_t)CST_VAX7 * npad + c] = sc.vax7;
+        }
+        HIP_TRY(G->beta0.upload(hb));
+        HIP_TRY(G->cst.upload(hc));
+    }
+    // noise draws z[t][c] (env.scala:91) and the shared action stream (DDQNAgent.scala:26-32):
+    // every rollout builds fresh envs and agents, so these are the same for all grid points.
+    {
+        const int T = d->steps > 0 ? d->steps : 1;
+        std::vector<double> hz((size_t)T * npad, 0.0);
+        if (d->heterogeneous) {
+            for (int c = 0; c < n; ++c) {
+                JavaRandom r(c + 42);  // Calibrate.scala:36
+                for (int t = 0; t < d->steps; ++t) hz[(size_t)t * npad + c] = r.nextGaussian();
+            }
+        } else {
+            JavaRandom r(7);  // Calibrate.scala:32: every env is seeded 7
+            for (int t = 0; t < d->steps; ++t) {
+                const double z = r.nextGaussian();
+                for (int c = 0; c < n; ++c) hz[(size_t)t * npad + c] = z;
+            }
+        }
+        HIP_TRY(G->noise.upload(hz));
+        std::vector<int8_t> ha((size_t)T * npad, 0);
+        AgentStream ag;  // all agents share seed 9 and the hyper-parameters: one stream serves all
+        G->greedy_steps.clear();
+        for (int t = 0; t < d->steps; ++t) {
+            const int act = ag.act(hp);
+            if (act == kGreedyAction) G->greedy_steps.push_back(t);
+            for (int c = 0; c < n; ++c) ha[(size_t)t * npad + c] = (int8_t)(act == kGreedyAction ? 0 : act);
+        }
+        HIP_TRY(G->actions.upload(ha));
+    }
+    if (!G->greedy_steps.empty()) {
+        std::vector<double> w1, w2, w3;
+        mlp_init(7, hp.hidden, 8, w1, w2, w3);  // untrained online network (DDQNAgent.scala:8)
+        rc = G->mlp.upload(hp.hidden, w1.data(), nullptr, w2.data(), nullptr, w3.data(), nullptr, hp.clip_q);
+        if (rc) return rc;
+    }
+    // targets (Calibrate.Targets maps as value + presence arrays)
+    {
+        std::vector<double> ta((size_t)n, 0.0), tp((size_t)n, 0.0);
+        std::vector<uint8_t> ha((size_t)n, 0), hk((size_t)n, 0);
+        for (int c = 0; c < n; ++c) {
+            if (d->has_arrive && d->has_arrive[c]) { ha[c] = 1; ta[c] = d->t_arrive[c]; }
+            if (d->has_peak && d->has_peak[c]) { hk[c] = 1; tp[c] = d->t_peak[c]; }
+        }
+        HIP_TRY(G->t_arrive.upload(ta));
+        HIP_TRY(G->t_peak.upload(tp));
+        HIP_TRY(G->has_arrive.upload(ha));
+        HIP_TRY(G->has_peak.upload(hk));
+    }
+    return EPI_OK;
+}
+
+EPI_API epi_grid* epi_grid_create(const epi_grid_desc* desc) {
+    if (!desc) { fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_create: null descriptor"); return nullptr; }
+    std::unique_ptr<epi_grid> G(new epi_grid());
+    if (grid_build(G.get(), desc) != EPI_OK) return nullptr;
+    return G.release();
+}
+
+EPI_API int32_t epi_grid_destroy(epi_grid* g) {
+    if (!g) return EPI_OK;
+    (void)hipSetDevice(g->device);
+    delete g;
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_grid_status(epi_grid* g) {
+    if (!g) return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_status: null handle");
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (!g->pending) return EPI_OK;
+    g->pending = false;
+    return collect_errors(g->work.err, g->last_count, g->last_g_begin);
+}
+
+EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, double* loss, int32_t* arrival, double* peak,
+                             int32_t out_on_device, void* stream) {
+    if (!g) return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_run: null handle");
+    const int G = g->n_beta * g->n_travel;
+    if (g_begin < 0 || g_count < 0 || g_begin + g_count > G) return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_run: slab [%d,%d) outside the %d grid points", g_begin, g_begin + g_count, G);
+    if (g_count == 0) return EPI_OK;
+    HIP_TRY(hipSetDevice(g->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int32_t rc = g->work.ensure(g_count, g->npad);
+    if (rc) return rc;
+    const int n = g->n, npad = g->npad;
+
+    double* d_loss = loss;
+    int32_t* d_arr = arrival;
+    double* d_pk = peak;
+    if (!out_on_device) {
+        HIP_TRY(g->loss_tmp.ensure(sizeof(double) * (size_t)g_count));
+        d_loss = g->loss_tmp.as<double>();
+        if (arrival) { HIP_TRY(g->arrival_tmp.ensure(sizeof(int32_t) * (size_t)g_count * n)); d_arr = g->arrival_tmp.as<int32_t>(); }
+        if (peak) { HIP_TRY(g->peak_tmp.ensure(sizeof(double) * (size_t)g_count * n)); d_pk = g->peak_tmp.as<double>(); }
+    }
+
+    InitArgs ia{};
+    ia.n = n; ia.npad = npad; ia.count = g_count; ia.seed_idx = g->seed_idx;
+    ia.pop = g->graph.pop.as<int32_t>();
+    ia.base_cap = g->base.hosp_cap;
+    ia.r0 = (int32_t)g->base.r; ia.d0 = (int32_t)g->base.d; ia.v0 = (int32_t)g->base.v; ia.t0 = g->base.t;
+    ia.st = g->work.st.as<int32_t>(); ia.cap = g->work.cap.as<double>(); ia.tcur = g->work.tcur.as<int32_t>();
+    ia.arrival = g->work.arrival.as<int32_t>(); ia.peak = g->work.peak.as<int32_t>(); ia.err = g->work.err.as<int32_t>();
+    HIP_TRY(launch_init(ia, s));
+
+    EpisodeArgs ea{};
+    ea.n = n; ea.npad = npad; ea.count = g_count;
+    ea.seed_idx = g->seed_idx; ea.n_travel = g->n_travel; ea.g_begin = g_begin;
+    ea.step_t_max = g->steps;  // world.stepOne(cfg.stepsPerEpoch), Calibrate.scala:70
+    ea.validate = 1;
+    ea.q = g->graph.q.as<double>(); ea.sumw = g->graph.sumw.as<double>();
+    ea.qseed = g->qseed.as<double>(); ea.sumw_seed = g->sumw_seed.as<double>();
+    ea.beta0 = g->beta0.as<double>(); ea.beta_rows = g->n_beta > 0 ? g->n_beta : 1;
+    ea.cst = g->cst.as<double>();
+    ea.actions = g->actions.as<int8_t>(); ea.act_t0 = 0;
+    ea.noise = g->noise.as<double>(); ea.noise_t0 = 0;
+    ea.st = ia.st; ea.cap = ia.cap; ea.tcur = ia.tcur; ea.arrival = ia.arrival; ea.peak = ia.peak; ea.err = ia.err;
+
+    int t0 = 0;
+    for (int gs : g->greedy_steps) {
+        if (gs > t0) {
+            ea.t_begin = t0; ea.t_end = gs; ea.act_episode = nullptr;
+            HIP_TRY(launch_episode(ea, s));
+        }
+        MlpArgs ma{};
+        ma.rows = g_count * n; ma.n = n; ma.npad = npad;
+        ma.state_t_max = g->base.t_max;
+        ma.st = ia.st; ma.cap = ia.cap; ma.tcur = ia.tcur; ma.plane = (size_t)g_count * npad;
+        g->mlp.fill(ma);
+        ma.act_episode = g->work.act_ep.as<int8_t>();
+        HIP_TRY(launch_mlp(ma, s));
+        ea.t_begin = gs; ea.t_end = gs + 1; ea.act_episode = ma.act_episode;
+        HIP_TRY(launch_episode(ea, s));
+        t0 = gs + 1;
+    }
+    if (t0 < g->steps) {
+        ea.t_begin = t0; ea.t_end = g->steps; ea.act_episode = nullptr;
+        HIP_TRY(launch_episode(ea, s));
+    }
+
+    LossArgs la{};
+    la.n = n; la.npad = npad; la.count = g_count; la.steps = g->steps;
+    la.arrival = ia.arrival; la.peak = ia.peak;
+    la.t_arrive = g->t_arrive.as<double>(); la.has_arrive = g->has_arrive.as<uint8_t>();
+    la.t_peak = g->t_peak.as<double>(); la.has_peak = g->has_peak.as<uint8_t>();
+    la.loss = d_loss; la.arrival_out = d_arr; la.peak_out = d_pk;
+    HIP_TRY(launch_loss(la, s));
+
+    g->pending = true;
+    g->last_count = g_count;
+    g->last_g_begin = g_begin;
+    if (out_on_device) return EPI_OK;
+
+    HIP_TRY(hipStreamSynchronize(s));
+    if (loss) HIP_TRY(hipMemcpy(loss, d_loss, sizeof(double) * (size_t)g_count, hipMemcpyDeviceToHost));
+    if (arrival) HIP_TRY(hipMemcpy(arrival, d_arr, sizeof(int32_t) * (size_t)g_count * n, hipMemcpyDeviceToHost));
+    if (peak) HIP_TRY(hipMemcpy(peak, d_pk, sizeof(double) * (size_t)g_count * n, hipMemcpyDeviceToHost));
+    return epi_grid_status(g);
+}
+
+EPI_API int32_t epi_calibrate_grid(const epi_grid_desc* desc, double* loss, int32_t* arrival, double* peak, int32_t* best_idx,
+                                   double* best_loss) {
+    if (!desc) return fail(EPI_ERR_BAD_ARGUMENT, "epi_calibrate_grid: null descriptor");
+    const int G = desc->n_beta * desc->n_travel;
+    std::vector<double> tmp;
+    if (!loss) { tmp.resize((size_t)(G > 0 ? G : 1)); loss = tmp.data(); }
+    epi_grid* g = epi_grid_create(desc);
+    if (!g) return g_last_code ? g_last_code : EPI_ERR_DEVICE;
+    int32_t rc = epi_grid_run(g, 0, G, loss, arrival, peak, 0, nullptr);
+    epi_grid_destroy(g);
+    if (rc) return rc;
+    // bestPair defaults to the first grid point (Calibrate.scala:97): index 0
+    return epi_grid_argmin(loss, G, best_idx, best_loss);
+}
+
+// ================================================================================================
+// batched worlds
+// ================================================================================================
+static int32_t world_build(epi_world* Wd, const epi_world_desc* d) {
+    if (d->n < 1 || d->batch < 1) return fail(EPI_ERR_BAD_ARGUMENT, "world: n = %d, batch = %d", d->n, d->batch);
+    if (d->n > kMaxDenseN)
+        return fail(EPI_ERR_BAD_ARGUMENT, "world: n = %d countries exceeds the %d the register-resident row kernel holds", d->n, kMaxDenseN);
+    if (!d->pop || !d->env || !d->prof || d->seed_idx < 0 || d->seed_idx >= d->n) return fail(EPI_ERR_BAD_ARGUMENT, "world: null input or bad seed index");
+    int32_t rc = check_base_state(d->base, "world");
+    if (rc) return rc;
+    if (d->validate) {
+        rc = assert_initial(d->base);
+        if (rc) return rc;
+    }
+    rc = use_device(d->device);
+    if (rc) return rc;
+    Wd->device = d->device;
+    Wd->n = d->n; Wd->batch = d->batch; Wd->seed_idx = d->seed_idx; Wd->validate = d->validate;
+    Wd->base = d->base;
+    rc = Wd->graph.build(d->n, d->pop, d->conn, d->csr_rowptr, d->csr_col, d->csr_val);
+    if (rc) return rc;
+    const int n = d->n, npad = Wd->graph.npad;
+    Wd->npad = npad;
+    std::vector<double> hb((size_t)npad, 0.0), hc((size_t)CST_COUNT * npad, 0.0);
+    std::vector<RewardConsts> hr((size_t)npad);
+    std::memset(hr.data(), 0, hr.size() * sizeof(RewardConsts));
+    for (int c = 0; c < n; ++c) {
+        const StepConsts sc = make_step_consts(d->env[c], d->prof[c]);
+        hb[c] = sc.beta0;
+        hc[(size_t)CST_GAMMA * npad + c] = sc.gamma;
+        hc[(size_t)CST_IFR0 * npad + c] = sc.ifr0;
+        hc[(size_t)CST_CNOISE * npad + c] = sc.cnoise;
+        hc[(size_t)CST_EFF1 * npad + c] = sc.eff1;
+        hc[(size_t)CST_EFF2 * npad + c] = sc.eff2;
+        hc[(size_t)CST_EFF3 * npad + c] = sc.eff3;
+        hc[(size_t)CST_SURGE * npad + c] = sc.surge;
+        hc[(size_t)CST_VAX6 * npad + c] = sc.vax6;
+        hc[(size_t)CST_VAX7 * npad + c] = sc.vax7;
+        hr[c] = make_reward_consts(d->env[c], d->prof[c]);
+    }
+    HIP_TRY(Wd->beta0.upload(hb));
+    HIP_TRY(Wd->cst.upload(hc));
+    HIP_TRY(Wd->rwd.upload(hr));
+    Wd->env_seeds.assign((size_t)n, 42);  // EpidemicEnv default seed (env.scala:40)
+    if (d->env_seeds) Wd->env_seeds.assign(d->env_seeds, d->env_seeds + n);
+    Wd->env_rnd.clear();
+    for (int c = 0; c < n; ++c) Wd->env_rnd.emplace_back((int64_t)Wd->env_seeds[c]);
+    rc = Wd->work.ensure(d->batch, npad);
+    if (rc) return rc;
+    const size_t cells = (size_t)d->batch * npad;
+    HIP_TRY(Wd->act_dev.ensure(cells));
+    HIP_TRY(Wd->gauss_dev.ensure(cells * sizeof(double)));
+    HIP_TRY(Wd->reward_dev.ensure(cells * sizeof(double)));
+    HIP_TRY(Wd->flow_s.ensure(cells * sizeof(int32_t)));
+    HIP_TRY(Wd->flow_i.ensure(cells * sizeof(int32_t)));
+    return EPI_OK;
+}
+
+static int32_t world_init_states(epi_world* w) {
+    InitArgs ia{};
+    ia.n = w->n; ia.npad = w->npad; ia.count = w->batch; ia.seed_idx = w->seed_idx;
+    ia.pop = w->graph.pop.as<int32_t>();
+    ia.base_cap = w->base.hosp_cap;
+    ia.r0 = (int32_t)w->base.r; ia.d0 = (int32_t)w->base.d; ia.v0 = (int32_t)w->base.v; ia.t0 = w->base.t;
+    ia.st = w->work.st.as<int32_t>(); ia.cap = w->work.cap.as<double>(); ia.tcur = w->work.tcur.as<int32_t>();
+    ia.arrival = w->work.arrival.as<int32_t>(); ia.peak = w->work.peak.as<int32_t>(); ia.err = w->work.err.as<int32_t>();
+    HIP_TRY(launch_init(ia, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return EPI_OK;
+}
+
+EPI_API epi_world* epi_world_create(const epi_world_desc* desc) {
+    if (!desc) { fail(EPI_ERR_BAD_ARGUMENT, "epi_world_create: null descriptor"); return nullptr; }
+    std::unique_ptr<epi_world> w(new epi_world());
+    if (world_build(w.get(), desc) != EPI_OK) return nullptr;
+    if (world_init_states(w.get()) != EPI_OK) return nullptr;
+    return w.release();
+}
+
+EPI_API int32_t epi_world_destroy(epi_world* w) {
+    if (!w) return EPI_OK;
+    (void)hipSetDevice(w->device);
+    delete w;
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_world_reset(epi_world* w) {
+    if (!w) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_reset: null handle");
+    HIP_TRY(hipSetDevice(w->device));
+    return world_init_states(w);
+}
+
+static int32_t world_download_states(epi_world* w, epi_state* out) {
+    const int n = w->n, npad = w->npad, B = w->batch;
+    const size_t cells = (size_t)B * npad;
+    std::vector<int32_t> st(cells * 5), tc(cells);
+    std::vector<double> cap(cells);
+    HIP_TRY(hipMemcpy(st.data(), w->work.st.p, st.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tc.data(), w->work.tcur.p, tc.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cap.data(), w->work.cap.p, cap.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < n; ++c) {
+            const size_t idx = (size_t)b * npad + c;
+            epi_state& o = out[(size_t)b * n + c];
+            o = w->base;
+            o.s = st[0 * cells + idx]; o.i = st[1 * cells + idx]; o.r = st[2 * cells + idx];
+            o.d = st[3 * cells + idx]; o.v = st[4 * cells + idx];
+            o.hosp_cap = cap[idx];
+            o.t = tc[idx];
+        }
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_world_get_states(epi_world* w, epi_state* out) {
+    if (!w || !out) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_get_states: null argument");
+    HIP_TRY(hipSetDevice(w->device));
+    return world_download_states(w, out);
+}
+
+EPI_API int32_t epi_world_set_states(epi_world* w, const epi_state* in) {
+    if (!w || !in) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_set_states: null argument");
+    HIP_TRY(hipSetDevice(w->device));
+    const int n = w->n, npad = w->npad, B = w->batch;
+    const size_t cells = (size_t)B * npad;
+    std::vector<int32_t> st(cells * 5, 0), tc(cells, 0);
+    std::vector<double> cap(cells, 1.0);
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < n; ++c) {
+            const epi_state& s = in[(size_t)b * n + c];
+            if (!is_count(s.s) || !is_count(s.i) || !is_count(s.r) || !is_count(s.d) || !is_count(s.v) || !std::isfinite(s.hosp_cap))
+                return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_set_states: instance %d country %d: compartments must be non-negative integers below 2^31", b, c);
+            const size_t idx = (size_t)b * npad + c;
+            st[0 * cells + idx] = (int32_t)s.s; st[1 * cells + idx] = (int32_t)s.i; st[2 * cells + idx] = (int32_t)s.r;
+            st[3 * cells + idx] = (int32_t)s.d; st[4 * cells + idx] = (int32_t)s.v;
+            cap[idx] = s.hosp_cap;
+            tc[idx] = s.t;
+        }
+    HIP_TRY(hipMemcpy(w->work.st.p, st.data(), st.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(w->work.tcur.p, tc.data(), tc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(w->work.cap.p, cap.data(), cap.size() * sizeof(double), hipMemcpyHostToDevice));
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_world_set_mlp(epi_world* w, int32_t hidden, const double* W1, const double* b1, const double* W2,
+                                  const double* b2, const double* W3, const double* b3, double clip_q) {
+    if (!w || !W1 || !W2 || !W3) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_set_mlp: null argument");
+    HIP_TRY(hipSetDevice(w->device));
+    int32_t rc = w->mlp.upload(hidden, W1, b1, W2, b2, W3, b3, clip_q);
+    if (rc) return rc;
+    w->mlp_set = true;
+    return EPI_OK;
+}
+
+static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy, const double* gauss, int32_t t_max,
+                               epi_state* out_states, double* out_rewards, int32_t* out_actions) {
+    const int n = w->n, npad = w->npad, B = w->batch;
+    const size_t cells = (size_t)B * npad;
+    HIP_TRY(hipSetDevice(w->device));
+    // noise draws: caller-supplied, or one JVM-compatible stream per country shared by all instances
+    std::vector<double> hz(cells, 0.0);
+    if (gauss) {
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < n; ++c) {
+                const double z = gauss[(size_t)b * n + c];
+                if (!std::isfinite(z)) return fail(EPI_ERR_BAD_ARGUMENT, "world step: gauss[%d][%d] is not finite", b, c);
+                hz[(size_t)b * npad + c] = z;
+            }
+    } else {
+        for (int c = 0; c < n; ++c) {
+            const double z = w->env_rnd[c].nextGaussian();
+            for (int b = 0; b < B; ++b) hz[(size_t)b * npad + c] = z;
+        }
+    }
+    HIP_TRY(hipMemcpy(w->gauss_dev.p, hz.data(), cells * sizeof(double), hipMemcpyHostToDevice));
+    if (greedy) {
+        if (!w->mlp_set) return fail(EPI_ERR_BAD_ARGUMENT, "world greedy step: call epi_world_set_mlp first");
+        MlpArgs ma{};
+        ma.rows = B * n; ma.n = n; ma.npad = npad;
+        ma.state_t_max = w->base.t_max;
+        ma.st = w->work.st.as<int32_t>(); ma.cap = w->work.cap.as<double>(); ma.tcur = w->work.tcur.as<int32_t>();
+        ma.plane = cells;
+        w->mlp.fill(ma);
+        ma.act_episode = w->act_dev.as<int8_t>();
+        HIP_TRY(launch_mlp(ma, nullptr));
+    } else {
+        std::vector<int8_t> ha(cells, 0);
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < n; ++c) {
+                const int32_t a = actions[(size_t)b * n + c];
+                ha[(size_t)b * npad + c] = (int8_t)(a < 0 ? 0 : (a > 7 ? 7 : a));  // Action.fromId clamps
+            }
+        HIP_TRY(hipMemcpy(w->act_dev.p, ha.data(), cells, hipMemcpyHostToDevice));
+    }
+    EpisodeArgs ea{};
+    ea.n = n; ea.npad = npad; ea.count = B;
+    ea.seed_idx = w->seed_idx; ea.n_travel = 0; ea.g_begin = 0;
+    ea.t_begin = 0; ea.t_end = 1;
+    ea.step_t_max = t_max;
+    ea.validate = w->validate;
+    ea.q = w->graph.q.as<double>(); ea.sumw = w->graph.sumw.as<double>();
+    ea.qseed = nullptr; ea.sumw_seed = nullptr;
+    ea.beta0 = w->beta0.as<double>(); ea.beta_rows = 1;
+    ea.cst = w->cst.as<double>();
+    ea.actions = nullptr; ea.act_episode = w->act_dev.as<int8_t>();
+    ea.noise = nullptr; ea.noise_episode = w->gauss_dev.as<double>();
+    ea.st = w->work.st.as<int32_t>(); ea.cap = w->work.cap.as<double>(); ea.tcur = w->work.tcur.as<int32_t>();
+    ea.arrival = w->work.arrival.as<int32_t>(); ea.peak = w->work.peak.as<int32_t>(); ea.err = w->work.err.as<int32_t>();
+    ea.rwd = w->rwd.as<RewardConsts>(); ea.reward_out = w->reward_dev.as<double>();
+    ea.flow_s = w->flow_s.as<int32_t>(); ea.flow_i = w->flow_i.as<int32_t>();
+    HIP_TRY(hipMemset(w->work.err.p, 0, (size_t)B * 4 * sizeof(int32_t)));
+    HIP_TRY(launch_episode(ea, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    w->have_flows = true;
+    int32_t rc = collect_errors(w->work.err, B, 0);
+    if (rc) return rc;
+    if (out_states) {
+        rc = world_download_states(w, out_states);
+        if (rc) return rc;
+    }
+    if (out_rewards) {
+        std::vector<double> hr(cells);
+        HIP_TRY(hipMemcpy(hr.data(), w->reward_dev.p, cells * sizeof(double), hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < n; ++c) out_rewards[(size_t)b * n + c] = hr[(size_t)b * npad + c];
+    }
+    if (out_actions) {
+        std::vector<int8_t> ha(cells);
+        HIP_TRY(hipMemcpy(ha.data(), w->act_dev.p, cells, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < n; ++c) out_actions[(size_t)b * n + c] = ha[(size_t)b * npad + c];
+    }
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_world_step(epi_world* w, const int32_t* actions, const double* gauss, int32_t t_max,
+                               epi_state* out_states, double* out_rewards) {
+    if (!w || !actions) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_step: null argument");
+    return world_step_impl(w, actions, false, gauss, t_max, out_states, out_rewards, nullptr);
+}
+
+EPI_API int32_t epi_world_step_greedy(epi_world* w, const double* gauss, int32_t t_max, epi_state* out_states,
+                                      double* out_rewards, int32_t* out_actions) {
+    if (!w) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_step_greedy: null handle");
+    return world_step_impl(w, nullptr, true, gauss, t_max, out_states, out_rewards, out_actions);
+}
+
+EPI_API int32_t epi_world_last_flows(epi_world* w, int32_t* moved_s, int32_t* moved_i) {
+    if (!w || !moved_s || !moved_i) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_last_flows: null argument");
+    if (!w->have_flows) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_last_flows: no step has run yet");
+    HIP_TRY(hipSetDevice(w->device));
+    const int n = w->n, npad = w->npad, B = w->batch;
+    const size_t cells = (size_t)B * npad;
+    std::vector<int32_t> a(cells), b2(cells);
+    HIP_TRY(hipMemcpy(a.data(), w->flow_s.p, cells * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(b2.data(), w->flow_i.p, cells * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < n; ++c) {
+            moved_s[(size_t)b * n + c] = a[(size_t)b * npad + c];
+            moved_i[(size_t)b * n + c] = b2[(size_t)b * npad + c];
+        }
+    return EPI_OK;
+}

@@ -1,0 +1,408 @@
+// Device-side building blocks (gfx950, wave64) for the metapopulation step.
+//
+// Everything here must reproduce the reference's IEEE-754 binary64 arithmetic one
+// rounding at a time: the translation unit is compiled with -ffp-contract=off, so
+// a*b+c is a multiply followed by an add exactly as on the JVM.  Reference paths
+// are relative to src/main/scala/epidemic/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/epi.h"
+
+namespace epi {
+
+// ---------------------------------------------------------------------------------------------
+// Per-country constants of EpidemicEnv.step that do not depend on the state (env.scala:59-101).
+// Each member is produced by the same operation sequence the reference runs every step, so
+// hoisting them changes no rounding.
+// ---------------------------------------------------------------------------------------------
+struct StepConsts {
+    double beta0;   // baseBeta * profile.betaMul                      env.scala:59
+    double gamma;   // baseGamma                                       :60
+    double ifr0;    // baseIFR * profile.ifrMul                        :61
+    double cnoise;  // noise * (0.2 + profile.noise * 1.5)             :90
+    double eff1;    // Distancing: economicResilience * 0.75 + 0.5     :66
+    double eff2;    // TravelBan: (1 - connectivityStrength)*0.4 + 0.4 :69
+    double eff3;    // Lockdown: economicResilience * 0.5 + 0.2        :72
+    double surge;   // SurgeCare: 1 + healthcareCapacity               :75
+    double vax6;    // TargetedVax: 0.02 * healthcareCapacity          :98
+    double vax7;    // MassVax: 0.05 * healthcareCapacity              :99
+};
+constexpr int kStepConstCount = 10;
+
+__host__ __device__ inline StepConsts make_step_consts(const epi_env_params& e, const epi_profile& p) {
+    StepConsts c;
+    c.beta0 = e.base_beta * p.beta_mul;
+    c.gamma = e.base_gamma;
+    c.ifr0 = e.base_ifr * p.ifr_mul;
+    c.cnoise = e.noise * (0.2 + p.noise * 1.5);
+    c.eff1 = p.econ_resilience * 0.75 + 0.5;
+    c.eff2 = (1.0 - p.connectivity) * 0.4 + 0.4;
+    c.eff3 = p.econ_resilience * 0.5 + 0.2;
+    c.surge = 1.0 + p.healthcare_capacity;
+    c.vax6 = 0.02 * p.healthcare_capacity;
+    c.vax7 = 0.05 * p.healthcare_capacity;
+    return c;
+}
+
+// Reward constants (env.scala:142-234), again hoisted without reordering any product.
+struct RewardConsts {
+    double health_w, gdp_f, hc_f, dens_f, age_f;
+    double cost[8];   // calculateExtremeActionCost(a) * economicWeight * extremeGDPFactor   :185
+    double bonus[8];  // riskFactor * npiBonus(a)                                            :191
+    double rmul;      // 1.0 + 0.75 * riskFactor
+    double clip_lo, clip_hi;
+};
+
+__host__ __device__ inline RewardConsts make_reward_consts(const epi_env_params& e, const epi_profile& p) {
+    RewardConsts c;
+    const double hc = p.healthcare_capacity, g = p.gdp_per_capita, dn = p.population_density;
+    c.health_w = hc > 0.8 ? 0.2 : (hc > 0.5 ? 0.6 : 0.9);
+    const double econ_w = 1.0 - c.health_w;
+    c.gdp_f = g > 50000 ? 0.3 : (g > 20000 ? 1.0 : (g > 5000 ? 2.5 : 5.0));
+    c.hc_f = hc > 0.8 ? 0.2 : (hc > 0.5 ? 1.0 : 8.0);
+    c.dens_f = dn > 400 ? 3.0 : (dn > 200 ? 2.0 : (dn > 100 ? 1.0 : 0.5));
+    c.age_f = 1.0 + p.age_elderly * 8.0;
+    const double base_cost[8] = {0.0, 0.05, 0.08, 0.15, 0.01, 0.06, 0.03, 0.05};
+    const double em = g > 50000 ? 0.3 : (g > 20000 ? 1.0 : (g > 5000 ? 3.0 : 8.0));
+    for (int a = 0; a < 8; ++a) {
+        const double mm = (a == 3 || a == 2) ? 1.0 + (1.0 - p.econ_resilience) * 2.0 : 1.0;
+        const double ac = base_cost[a] * em * mm * 30.0;
+        c.cost[a] = ac * econ_w * c.gdp_f;
+        double nb = 0.0;
+        if (a == 3) nb = 0.05 * p.econ_resilience;
+        else if (a == 2) nb = 0.03 * p.connectivity;
+        else if (a == 1) nb = 0.02;
+        else if (a == 6) nb = 0.02 * hc;
+        else if (a == 7) nb = 0.04 * hc;
+        c.bonus[a] = e.risk_factor * nb;
+    }
+    c.rmul = 1.0 + 0.75 * e.risk_factor;
+    c.clip_lo = -e.reward_clip * 3.0;
+    c.clip_hi = e.reward_clip;
+    return c;
+}
+
+#if defined(__HIPCC__)
+
+namespace dev {
+
+// ---------------------------------------------------------------------------------------------
+// Wave64 reductions on the DPP network (no LDS): four row steps, two row-broadcast steps,
+// result read from lane 63 as a wave-uniform scalar.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    v += dpp_or<0xB1, 0xf>(0u, v);   // quad_perm [1,0,3,2]
+    v += dpp_or<0x4E, 0xf>(0u, v);   // quad_perm [2,3,0,1]
+    v += dpp_or<0x141, 0xf>(0u, v);  // row_half_mirror
+    v += dpp_or<0x140, 0xf>(0u, v);  // row_mirror
+    v += dpp_or<0x142, 0xa>(0u, v);  // row_bcast15 -> rows 1,3
+    v += dpp_or<0x143, 0xc>(0u, v);  // row_bcast31 -> rows 2,3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+    v = max(v, dpp_or<0xB1, 0xf>(0u, v));
+    v = max(v, dpp_or<0x4E, 0xf>(0u, v));
+    v = max(v, dpp_or<0x141, 0xf>(0u, v));
+    v = max(v, dpp_or<0x140, 0xf>(0u, v));
+    v = max(v, dpp_or<0x142, 0xa>(0u, v));
+    v = max(v, dpp_or<0x143, 0xc>(0u, v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
+    v = min(v, dpp_or<0xB1, 0xf>(0xffffffffu, v));
+    v = min(v, dpp_or<0x4E, 0xf>(0xffffffffu, v));
+    v = min(v, dpp_or<0x141, 0xf>(0xffffffffu, v));
+    v = min(v, dpp_or<0x140, 0xf>(0xffffffffu, v));
+    v = min(v, dpp_or<0x142, 0xa>(0xffffffffu, v));
+    v = min(v, dpp_or<0x143, 0xc>(0xffffffffu, v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Sum of non-negative 64-bit values below 2^44 across the wave (world mass check,
+// WorldToy.scala:103-104,142-145): split at bit 22 so both halves fit a 32-bit wave sum.
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+    const uint32_t lo = wave_sum((uint32_t)(v & 0x3fffffu));
+    const uint32_t hi = wave_sum((uint32_t)(v >> 22));
+    return ((unsigned long long)hi << 22) + lo;
+}
+
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ __forceinline__ double clamp01(double x) { return fmax(0.0, fmin(1.0, x)); }  // env.scala:53
+
+// ---------------------------------------------------------------------------------------------
+// EpidemicEnv.allocateInt for three weights (env.scala:241-254), the S and I splits of
+// env.scala:107,113.  The stable descending sort of three fractions is a rank computation:
+// position(j) = #{k : f_k > f_j} + #{k < j : f_k == f_j}.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void alloc3(int32_t total, double w0, double w1, double w2, int32_t& a0, int32_t& a1,
+                                       int32_t& a2) {
+    a0 = a1 = a2 = 0;
+    const double sum = (w0 + w1) + w2;
+    if (total <= 0 || sum <= 0.0) return;
+    const double t = (double)total;
+    const double r0 = (w0 / sum) * t, r1 = (w1 / sum) * t, r2 = (w2 / sum) * t;
+    const double fl0 = floor(r0), fl1 = floor(r1), fl2 = floor(r2);
+    uint32_t b0 = (uint32_t)(int32_t)fl0, b1 = (uint32_t)(int32_t)fl1, b2 = (uint32_t)(int32_t)fl2;
+    const int32_t rem = (int32_t)((uint32_t)total - (b0 + b1 + b2));
+    const double f0 = r0 - fl0, f1 = r1 - fl1, f2 = r2 - fl2;
+    const int p0 = (f1 > f0) + (f2 > f0);
+    const int p1 = (f0 >= f1) + (f2 > f1);
+    const int p2 = (f0 >= f2) + (f1 >= f2);
+    b0 += (p0 < rem);
+    b1 += (p1 < rem);
+    b2 += (p2 < rem);
+    a0 = (int32_t)b0; a1 = (int32_t)b1; a2 = (int32_t)b2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// EpidemicEnv.step on integer compartments (env.scala:58-133).  Inputs are the already rounded,
+// non-negative counts s0..v0 (env.scala:81-85), hospCap, the action id 0..7 and the Gaussian draw.
+// ---------------------------------------------------------------------------------------------
+struct LocalOut {
+    int32_t s, i, r, d, v;
+    double cap;
+};
+
+__device__ __forceinline__ LocalOut local_step(const StepConsts& c, int32_t s0, int32_t i0, int32_t r0, int32_t d0,
+                                               int32_t v0, double cap, int act, double z) {
+    double beta = c.beta0, gamma = c.gamma;
+    if (act == 1) beta *= c.eff1;
+    else if (act == 2) beta *= c.eff2;
+    else if (act == 3) beta *= c.eff3;
+    else if (act == 5) { cap *= c.surge; gamma *= 1.3; }
+
+    const uint32_t us = (uint32_t)s0, ui = (uint32_t)i0, ur = (uint32_t)r0, ud = (uint32_t)d0, uv = (uint32_t)v0;
+    const int32_t pop0 = (int32_t)(us + ui + ur + ud + uv);
+    const double mix = fmax(1.0, (double)(int32_t)(us + ui + ur));
+
+    const double stoch = 1.0 + c.cnoise * z;
+    const double effBeta = clamp01(beta * stoch);
+    const double effGamma = clamp01(gamma * stoch);
+    const double effIFR = clamp01((((double)i0 > cap) ? c.ifr0 * 6.0 : c.ifr0) * stoch);
+    const double vax = act == 6 ? c.vax6 : (act == 7 ? c.vax7 : 0.0);
+
+    const double pInf = clamp01(effBeta * ((double)i0 / mix));
+    const double pVax = clamp01(vax);
+    int32_t sStay, sInf, sVax;
+    alloc3(s0, fmax(0.0, 1.0 - pInf - pVax), pInf, pVax, sStay, sInf, sVax);
+
+    const double pRec = clamp01(effGamma);
+    const double pDie = clamp01(effIFR);
+    int32_t iStay, rec, die;
+    alloc3(i0, fmax(0.0, 1.0 - pRec - pDie), pRec, pDie, iStay, rec, die);
+
+    uint32_t sN = us - (uint32_t)sInf - (uint32_t)sVax;
+    const uint32_t iN = (uint32_t)iStay + (uint32_t)sInf;
+    const uint32_t rN = ur + (uint32_t)rec;
+    const uint32_t dN = ud + (uint32_t)die;
+    const uint32_t vN = uv + (uint32_t)sVax;
+    const int32_t resid = (int32_t)((uint32_t)pop0 - (sN + iN + rN + dN + vN));
+    if (resid != 0) sN = (uint32_t)max(0, (int32_t)(sN + (uint32_t)resid));
+
+    LocalOut o;
+    o.s = (int32_t)sN; o.i = (int32_t)iN; o.r = (int32_t)rN; o.d = (int32_t)dN; o.v = (int32_t)vN;
+    o.cap = cap;
+    return o;
+}
+
+// calculateExtremeHeterogeneousReward (env.scala:142-194) from the previous I and D (as the
+// doubles held in State) and the next integer state.
+__device__ __forceinline__ double reward_of(const RewardConsts& c, double prev_i, double prev_d, const LocalOut& nx,
+                                            int act) {
+    const double ns = (double)nx.s, ni = (double)nx.i, nr = (double)nx.r, nd = (double)nx.d;
+    const double Nnext = fmax(1.0, ns + ni + nr + nd);
+    const double di = (ni - prev_i) / Nnext;
+    const double dd = (nd - prev_d) / Nnext;
+    const double overflow = fmax(0.0, ni / fmax(1.0, nx.cap) - 1.0);
+    const double infectionPenalty = di * 200.0 * c.dens_f * c.health_w * c.gdp_f;
+    const double mortalityPenalty = dd * 2000.0 * c.age_f * c.hc_f * c.health_w;
+    const double healthcarePenalty = overflow * 1000.0 * c.health_w * c.hc_f;
+    const double baseReward = -(infectionPenalty + mortalityPenalty + healthcarePenalty + c.cost[act]);
+    const double shaped = baseReward * c.rmul + c.bonus[act];
+    return fmax(c.clip_lo, fmin(c.clip_hi, shaped));
+}
+
+// Math.round(x).toInt clamped at 0 (env.scala:81-85) for a finite double.
+__device__ __forceinline__ int32_t round_count(double x) {
+    const double fl = floor(x);
+    double r = (x - fl >= 0.5) ? fl + 1.0 : fl;
+    long long l;
+    if (r >= 9223372036854775807.0) l = 0x7fffffffffffffffLL;
+    else if (r <= -9223372036854775808.0) l = (long long)0x8000000000000000ULL;
+    else l = (long long)r;
+    const int32_t w = (int32_t)(uint32_t)(unsigned long long)l;
+    return w > 0 ? w : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Largest-remainder apportionment of one wide row held in registers: the mobility split of
+// WorldToy.scala:117-118 (EpidemicEnv.allocateInt, env.scala:241-254) for n <= 64*R weights.
+//
+// Layout: column j lives in slot r = j / 64 of lane j % 64.  qrow[j] is the already normalised
+// weight w_j / sumW (0 for the diagonal and for padding columns j >= n), 64*R entries.
+//
+// The reference sorts the fractional parts (stable, descending) and hands one unit to the first
+// `rem`.  Here the rem-th largest fraction is found by counting: the high 32 bits of a
+// non-negative double order like the double itself, so a threshold K with
+// #{hi32(frac) >= K} == rem selects exactly the rem largest fractions.  The threshold is
+// bracketed by interpolation with a bisection safeguard.  When no such K exists two or more
+// fractions share the pivot's high word; that case is finished exactly on the low words and,
+// for identical fractions, in ascending column order (tie_select).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double frac_of(double raw) { return __builtin_amdgcn_fract(raw); }
+
+__device__ __forceinline__ double from_hi_word(uint32_t hi) { return __hiloint2double((int)hi, 0); }
+
+__device__ __forceinline__ uint32_t next_threshold(uint32_t lo, uint32_t hi, int clo, int chi, int rem, int it) {
+    uint32_t mid;
+    const uint32_t span = hi - lo;
+    if (it % 3 == 2) {
+        mid = lo + (span >> 1);
+    } else {
+        // fraction of the way from lo (count clo) to hi (count chi) at which the count reaches rem
+        const float f = ((float)(clo - rem) + 0.5f) * __frcp_rn((float)(clo - chi));
+        if ((it & 1) == 0) {  // counts linear in the value
+            const double vlo = from_hi_word(lo), vhi = from_hi_word(hi);
+            const double t = vlo + (vhi - vlo) * (double)f;
+            mid = (uint32_t)__double2hiint(t);
+        } else {  // counts linear in the logarithm (the high word is exponent-major)
+            const uint32_t reach = 48u << 20;
+            const uint32_t lk = (span > reach) ? hi - reach : lo;
+            mid = lk + (uint32_t)((float)(hi - lk) * f);
+        }
+    }
+    mid = max(mid, lo + 1u);
+    mid = min(mid, hi - 1u);
+    return mid;
+}
+
+// Exact finish for fractions whose high word equals K.  Members are the columns j < n with
+// hi32(frac_j) == K; `m` of them are selected by (low word descending, column ascending).
+// Returns a per-lane bit mask over the slots r.  Fractions are recomputed from the row in
+// memory; this path is rare.
+template <int R>
+__device__ __noinline__ uint32_t tie_select(const double* __restrict__ qrow, double Ed, uint32_t K, int m, int n,
+                                            int lane) {
+    uint32_t mn = 0xffffffffu, mx = 0u;
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+        const int j = r * 64 + lane;
+        const double fr = frac_of(qrow[j] * Ed);
+        if (j < n && (uint32_t)__double2hiint(fr) == K) {
+            const uint32_t l = (uint32_t)__double2loint(fr);
+            mn = min(mn, l);
+            mx = max(mx, l);
+        }
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    unsigned long long Llo = mn, Lhi = (unsigned long long)mx + 1ull;
+    int c_hi = 0;
+    while (Lhi - Llo > 1ull) {
+        const unsigned long long mid = Llo + ((Lhi - Llo) >> 1);
+        uint32_t c = 0, sel = 0;
+#pragma unroll 1
+        for (int r = 0; r < R; ++r) {
+            const int j = r * 64 + lane;
+            const double fr = frac_of(qrow[j] * Ed);
+            const bool in = j < n && (uint32_t)__double2hiint(fr) == K && (unsigned long long)(uint32_t)__double2loint(fr) >= mid;
+            c += in;
+            sel |= (uint32_t)in << r;
+        }
+        c = wave_sum(c);
+        if ((int)c == m) return sel;
+        if ((int)c > m) Llo = mid;
+        else { Lhi = mid; c_hi = (int)c; }
+    }
+    // fractions identical to the pivot: ascending column order
+    const int m2 = m - c_hi;
+    int run = 0;
+    uint32_t sel = 0;
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+        const int j = r * 64 + lane;
+        const double fr = frac_of(qrow[j] * Ed);
+        const bool mem = j < n && (uint32_t)__double2hiint(fr) == K;
+        const uint32_t l = (uint32_t)__double2loint(fr);
+        const bool above = mem && (unsigned long long)l > Llo;
+        const bool eq = mem && (unsigned long long)l == Llo;
+        const unsigned long long mask = __ballot(eq);
+        const int pre = (int)lanes_below(mask);
+        if (above || (eq && run + pre < m2)) sel |= 1u << r;
+        run += __popcll(mask);
+    }
+    return sel;
+}
+
+// Adds allocateInt(E, row)[j] into acc[r] for every column except `diag` (WorldToy.scala:121 drops
+// the origin's own entry).  E > 0.  All 64 lanes must be active.
+template <int R>
+__device__ __forceinline__ void apportion_row(int32_t E, int n, int diag, const double* __restrict__ qrow,
+                                              uint32_t (&acc)[R], int lane) {
+    const double Ed = (double)E;
+    uint32_t key[R];
+    uint32_t bsum = 0, kmax = 0;
+    double q[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) q[r] = qrow[r * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double raw = q[r] * Ed;
+        const uint32_t b = (uint32_t)(int32_t)raw;  // raw >= 0: truncation is floor
+        key[r] = (uint32_t)__double2hiint(frac_of(raw));
+        acc[r] += b;
+        bsum += b;
+        kmax = max(kmax, key[r]);
+    }
+    const int32_t rem = (int32_t)((uint32_t)E - wave_sum(bsum));
+    if (rem <= 0) return;
+    if (rem >= n) {  // every real column gets a unit (the reference stops at frac.length)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j = r * 64 + lane;
+            acc[r] += (j < n && j != diag);
+        }
+        return;
+    }
+    uint32_t lo = 0, hi = wave_max(kmax) + 1u;
+    int clo = n, chi = 0, it = 0;
+    while (hi - lo > 1u) {
+        const uint32_t mid = next_threshold(lo, hi, clo, chi, rem, it);
+        uint32_t c = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) c += (key[r] >= mid);
+        c = wave_sum(c);
+        if ((int)c == rem) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] += (key[r] >= mid);
+            return;
+        }
+        if ((int)c > rem) { lo = mid; clo = (int)c; }
+        else { hi = mid; chi = (int)c; }
+        ++it;
+    }
+    // two or more fractions share the pivot's high word `lo`
+    const uint32_t sel = tie_select<R>(qrow, Ed, lo, rem - chi, n, lane);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int j = r * 64 + lane;
+        const bool take = (key[r] > lo) || ((sel >> r) & 1u);
+        acc[r] += (take && j != diag);
+    }
+}
+
+}  // namespace dev
+#endif  // __HIPCC__
+}  // namespace epi

@@ -1,0 +1,494 @@
+// HIP kernels (gfx950) for the metapopulation step and the calibration sweep.
+// Compiled with -ffp-contract=off: see epi_device.hpp.
+#include "epi_kernels.hpp"
+
+namespace epi {
+using namespace dev;
+
+// WorldToy.scala:115: min(X.toLong, floor(X * sumW + 1e-9).toLong).toInt for X >= 0, sumW >= 0.
+__device__ __forceinline__ int32_t export_count(int32_t X, double sumW) {
+    const double e = floor((double)X * sumW + 1e-9);
+    const long long l = (e >= 9223372036854775807.0) ? 0x7fffffffffffffffLL : (long long)e;
+    const long long m = (long long)X < l ? (long long)X : l;
+    return (int32_t)m;
+}
+
+__device__ __forceinline__ void record_error(int* sh_err, int code, int node, int t) {
+    if (atomicCAS(&sh_err[0], 0, code) == 0) {
+        sh_err[1] = node;
+        sh_err[2] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused dense episode kernel.  One workgroup = one episode (one world instance); thread c owns
+// country c; wave w apportions rows of the connection matrix.  Per step (WorldToy.stepOne,
+// WorldToy.scala:83-145):
+//   A  local dynamics per country (env.step), exports per row, local mass check
+//   B  mobility: rows are handed out dynamically to waves; each wave keeps the normalised row and
+//      the per-column allocations in registers (apportion_row) and accumulates column sums over
+//      all rows it processes; the wave totals are merged with LDS atomics
+//   C  apply inflow - export, advance t, arrival/peak metrics, world mass sums
+// The world mass totals of step t are compared by thread 0 during phase B of step t+1.
+// ---------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs a) {
+    constexpr int NP = R * 64;
+    __shared__ int32_t sh_s[NP], sh_i[NP], sh_r[NP], sh_d[NP], sh_v[NP];
+    __shared__ double sh_cap[NP];
+    __shared__ int32_t sh_expS[NP], sh_expI[NP];
+    __shared__ uint32_t sh_movS[NP], sh_movI[NP];
+    __shared__ unsigned long long sh_mass[2][2];
+    __shared__ int sh_next_row;
+    __shared__ int sh_err[4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int e = blockIdx.x;
+    const int g = a.g_begin + e;
+    const int n = a.n;
+    const int ti = a.n_travel > 0 ? g % a.n_travel : 0;
+    int bi = a.n_travel > 0 ? g / a.n_travel : g;
+    bi = bi < a.beta_rows ? bi : a.beta_rows - 1;
+    const size_t eoff = (size_t)e * NP;
+    const size_t plane = (size_t)a.count * NP;
+    const bool real = tid < n;
+
+    sh_s[tid] = a.st[0 * plane + eoff + tid];
+    sh_i[tid] = a.st[1 * plane + eoff + tid];
+    sh_r[tid] = a.st[2 * plane + eoff + tid];
+    sh_d[tid] = a.st[3 * plane + eoff + tid];
+    sh_v[tid] = a.st[4 * plane + eoff + tid];
+    sh_cap[tid] = a.cap[eoff + tid];
+    int32_t tcur = a.tcur[eoff + tid];
+    int32_t arrival = a.arrival[eoff + tid];
+    int32_t peak = a.peak[eoff + tid];
+    int32_t last_flow_s = 0, last_flow_i = 0;
+    if (tid == 0) {
+        sh_mass[0][0] = sh_mass[0][1] = sh_mass[1][0] = sh_mass[1][1] = 0ull;
+        sh_err[0] = sh_err[1] = sh_err[2] = sh_err[3] = 0;
+    }
+    const double my_sumw = real ? ((tid == a.seed_idx && a.qseed) ? a.sumw_seed[ti] : a.sumw[tid]) : 0.0;
+    __syncthreads();
+
+    for (int t = a.t_begin; t < a.t_end; ++t) {
+        // ------------------------------------------------------------------ phase A
+        if (tid == 0) sh_next_row = 0;
+        sh_movS[tid] = 0u;
+        sh_movI[tid] = 0u;
+        int32_t eS = 0, eI = 0;
+        unsigned long long mass_local = 0ull;
+        if (real) {
+            StepConsts c;
+            c.beta0 = a.beta0[(size_t)bi * NP + tid];
+            c.gamma = a.cst[CST_GAMMA * NP + tid];
+            c.ifr0 = a.cst[CST_IFR0 * NP + tid];
+            c.cnoise = a.cst[CST_CNOISE * NP + tid];
+            c.eff1 = a.cst[CST_EFF1 * NP + tid];
+            c.eff2 = a.cst[CST_EFF2 * NP + tid];
+            c.eff3 = a.cst[CST_EFF3 * NP + tid];
+            c.surge = a.cst[CST_SURGE * NP + tid];
+            c.vax6 = a.cst[CST_VAX6 * NP + tid];
+            c.vax7 = a.cst[CST_VAX7 * NP + tid];
+            int act = a.act_episode ? (int)a.act_episode[eoff + tid] : (int)a.actions[(size_t)(t - a.act_t0) * NP + tid];
+            act = act < 0 ? 0 : (act > 7 ? 7 : act);  // Action.fromId clamps (env.scala:18-20)
+            const double z = a.noise_episode ? a.noise_episode[eoff + tid] : a.noise[(size_t)(t - a.noise_t0) * NP + tid];
+            const int32_t s0 = sh_s[tid], i0 = sh_i[tid], r0 = sh_r[tid], d0 = sh_d[tid], v0 = sh_v[tid];
+            const double cap0 = sh_cap[tid];
+            const long long tb = (long long)s0 + i0 + r0 + d0 + v0;
+            const LocalOut o = local_step(c, s0, i0, r0, d0, v0, cap0, act, z);
+            const long long ta = (long long)o.s + o.i + o.r + o.d + o.v;
+            if (a.validate && ta != tb) record_error(sh_err, EPI_ERR_LOCAL_MASS, tid, tcur);
+            if ((o.s | o.i | o.r | o.d | o.v) < 0) record_error(sh_err, EPI_ERR_INT_RANGE, tid, tcur);
+            if (a.rwd) a.reward_out[eoff + tid] = reward_of(a.rwd[tid], (double)i0, (double)d0, o, act);
+            sh_s[tid] = o.s; sh_i[tid] = o.i; sh_r[tid] = o.r; sh_d[tid] = o.d; sh_v[tid] = o.v;
+            sh_cap[tid] = o.cap;
+            tcur += 1;  // env.scala:132
+            eS = export_count(max(0, o.s), my_sumw);
+            eI = export_count(max(0, o.i), my_sumw);
+            mass_local = ta > 0 ? (unsigned long long)ta : 0ull;
+        }
+        sh_expS[tid] = eS;
+        sh_expI[tid] = eI;
+        if (a.validate) {
+            const unsigned long long wsum = wave_sum_u64(mass_local);
+            if (lane == 0) atomicAdd(&sh_mass[t & 1][0], wsum);
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------------------ phase B
+        if (tid == 0 && a.validate && t > a.t_begin) {
+            const int p = (t - 1) & 1;
+            if (sh_mass[p][0] != sh_mass[p][1]) record_error(sh_err, EPI_ERR_WORLD_MASS, -1, t - 1);
+            sh_mass[p][0] = 0ull;
+            sh_mass[p][1] = 0ull;
+        }
+        {
+            uint32_t accS[R], accI[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { accS[r] = 0u; accI[r] = 0u; }
+            bool any = false;
+            for (;;) {
+                int row = 0;
+                if (lane == 0) row = atomicAdd(&sh_next_row, 1);
+                row = __builtin_amdgcn_readfirstlane(row);
+                if (row >= n) break;
+                const int32_t ES = __builtin_amdgcn_readfirstlane(sh_expS[row]);
+                const int32_t EI = __builtin_amdgcn_readfirstlane(sh_expI[row]);
+                if ((ES | EI) == 0) continue;
+                const double* __restrict__ qrow =
+                    (row == a.seed_idx && a.qseed) ? a.qseed + (size_t)ti * NP : a.q + (size_t)row * NP;
+                if (ES > 0) apportion_row<R>(ES, n, row, qrow, accS, lane);
+                if (EI > 0) apportion_row<R>(EI, n, row, qrow, accI, lane);
+                any = true;
+            }
+            if (any) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (accS[r]) atomicAdd(&sh_movS[r * 64 + lane], accS[r]);
+                    if (accI[r]) atomicAdd(&sh_movI[r * 64 + lane], accI[r]);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------------------ phase C
+        unsigned long long mass_move = 0ull;
+        if (real) {
+            const int32_t movedS = (int32_t)(sh_movS[tid] - (uint32_t)sh_expS[tid]);
+            const int32_t movedI = (int32_t)(sh_movI[tid] - (uint32_t)sh_expI[tid]);
+            const double ns = fmax(0.0, (double)sh_s[tid] + (double)movedS);  // WorldToy.scala:133
+            const double ni = fmax(0.0, (double)sh_i[tid] + (double)movedI);  // :134
+            if (ns > 2147483647.0 || ni > 2147483647.0) record_error(sh_err, EPI_ERR_INT_RANGE, tid, tcur);
+            const int32_t s3 = (int32_t)ns, i3 = (int32_t)ni;
+            sh_s[tid] = s3;
+            sh_i[tid] = i3;
+            tcur = min(tcur + 1, a.step_t_max);  // :135
+            if (arrival < 0 && i3 >= 10) arrival = t;  // Validation.arrivalTime, thresh 10.0
+            peak = max(peak, i3);                      // Validation.peakI
+            last_flow_s = movedS;
+            last_flow_i = movedI;
+            const long long tm = (long long)s3 + i3 + sh_r[tid] + sh_d[tid] + sh_v[tid];
+            mass_move = tm > 0 ? (unsigned long long)tm : 0ull;
+        }
+        if (a.validate) {
+            const unsigned long long wsum = wave_sum_u64(mass_move);
+            if (lane == 0) atomicAdd(&sh_mass[t & 1][1], wsum);
+        }
+        // No barrier here: phase A of the next step touches only this thread's own slots, and every
+        // wave has left the row loop before the barrier above.
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (a.validate && a.t_end > a.t_begin) {
+            const int p = (a.t_end - 1) & 1;
+            if (sh_mass[p][0] != sh_mass[p][1]) record_error(sh_err, EPI_ERR_WORLD_MASS, -1, a.t_end - 1);
+        }
+        if (sh_err[0] != 0 && a.err[e * 4] == 0) {
+            a.err[e * 4 + 1] = sh_err[1];
+            a.err[e * 4 + 2] = sh_err[2];
+            a.err[e * 4] = sh_err[0];
+        }
+    }
+    a.st[0 * plane + eoff + tid] = sh_s[tid];
+    a.st[1 * plane + eoff + tid] = sh_i[tid];
+    a.st[2 * plane + eoff + tid] = sh_r[tid];
+    a.st[3 * plane + eoff + tid] = sh_d[tid];
+    a.st[4 * plane + eoff + tid] = sh_v[tid];
+    a.cap[eoff + tid] = sh_cap[tid];
+    a.tcur[eoff + tid] = tcur;
+    a.arrival[eoff + tid] = arrival;
+    a.peak[eoff + tid] = peak;
+    if (a.flow_s) {
+        a.flow_s[eoff + tid] = last_flow_s;
+        a.flow_i[eoff + tid] = last_flow_i;
+    }
+}
+
+hipError_t launch_episode(const EpisodeArgs& a, hipStream_t s) {
+    if (a.count <= 0 || a.t_end <= a.t_begin) return hipSuccess;
+    const dim3 grid((unsigned)a.count);
+    switch (a.npad / 64) {
+        case 1: hipLaunchKernelGGL(episode_dense_kernel<1>, grid, dim3(64), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(episode_dense_kernel<2>, grid, dim3(128), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(episode_dense_kernel<4>, grid, dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL(episode_dense_kernel<8>, grid, dim3(512), 0, s, a); break;
+        case 16: hipLaunchKernelGGL(episode_dense_kernel<16>, grid, dim3(1024), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Initial states (WorldToy.scala:28-32) for `count` episodes.
+// ---------------------------------------------------------------------------------------------
+__global__ void init_states_kernel(const InitArgs a) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)a.count * a.npad;
+    if (idx >= total) return;
+    const int c = (int)(idx % a.npad);
+    const int e = (int)(idx / a.npad);
+    int32_t s = 0, i = 0, r = 0, d = 0, v = 0;
+    double cap = 1.0;
+    if (c < a.n) {
+        const int32_t pop = a.pop[c];
+        const double hc = a.base_cap * ((double)pop / 1000000.0);
+        cap = hc > 1.0 ? hc : 1.0;
+        if (c == a.seed_idx) {
+            i = (int32_t)(0.001 * (double)pop);
+            s = (int32_t)((uint32_t)pop - (uint32_t)i);
+        } else {
+            s = pop;
+        }
+        r = a.r0; d = a.d0; v = a.v0;
+    }
+    a.st[0 * total + idx] = s;
+    a.st[1 * total + idx] = i;
+    a.st[2 * total + idx] = r;
+    a.st[3 * total + idx] = d;
+    a.st[4 * total + idx] = v;
+    a.cap[idx] = cap;
+    a.tcur[idx] = a.t0;
+    a.arrival[idx] = -1;
+    a.peak[idx] = 0;
+    if (c < 4) a.err[e * 4 + c] = 0;
+}
+
+hipError_t launch_init(const InitArgs& a, hipStream_t s) {
+    const size_t total = (size_t)a.count * a.npad;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(init_states_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Loss of one grid point (Calibrate.scala:14-17,103-109): the two root-mean-squares are summed
+// over countries in order by one lane so that every rounding matches the sequential reference.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void loss_kernel(const LossArgs a) {
+    const int e = blockIdx.x;
+    const int lane = threadIdx.x;
+    const size_t eoff = (size_t)e * a.npad;
+    for (int c = lane; c < a.n; c += 64) {
+        const int32_t arr = a.arrival[eoff + c] < 0 ? a.steps : a.arrival[eoff + c];
+        if (a.arrival_out) a.arrival_out[(size_t)e * a.n + c] = arr;
+        if (a.peak_out) a.peak_out[(size_t)e * a.n + c] = (double)a.peak[eoff + c];
+    }
+    if (lane != 0 || a.loss == nullptr) return;
+    double sa = 0.0, sp = 0.0;
+    for (int c = 0; c < a.n; ++c) {
+        const double arr = (double)(a.arrival[eoff + c] < 0 ? a.steps : a.arrival[eoff + c]);
+        const double pk = (double)a.peak[eoff + c];
+        const double da = arr - (a.has_arrive[c] ? a.t_arrive[c] : arr);
+        const double dp = pk - (a.has_peak[c] ? a.t_peak[c] : pk);
+        const double qa = da * da, qp = dp * dp;
+        sa = (c == 0) ? qa : sa + qa;
+        sp = (c == 0) ? qp : sp + qp;
+    }
+    const double nn = fmax(1.0, (double)a.n);
+    const double arr_loss = sqrt(sa / nn);
+    const double pk_loss = sqrt(sp / nn);
+    a.loss[e] = 0.5 * arr_loss + 0.5 * pk_loss;
+}
+
+hipError_t launch_loss(const LossArgs& a, hipStream_t s) {
+    if (a.count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(loss_kernel, dim3((unsigned)a.count), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// DDQNAgent.actGreedy: State.features -> MLP.predict -> first argmax (env.scala:26-30,
+// MLP.scala:12-22, DDQNAgent.scala:22-23).  Every dot product is accumulated left to right with a
+// separate multiply and add, as `row.view.zip(x).map(w*xi).sum` does.
+// A workgroup of 128 threads evaluates MLP_ROWS states; thread u owns hidden unit u.
+// ---------------------------------------------------------------------------------------------
+constexpr int MLP_ROWS = 16;
+constexpr int MLP_MAXH = 128;
+
+__global__ __launch_bounds__(128) void mlp_greedy_kernel(const MlpArgs a) {
+    __shared__ double sh_x[MLP_ROWS][8];
+    __shared__ double sh_h1[MLP_ROWS][MLP_MAXH];
+    __shared__ double sh_h2[MLP_ROWS][MLP_MAXH];
+    __shared__ double sh_y[MLP_ROWS][8];
+    const int tid = threadIdx.x;
+    const int H = a.hidden;
+    const int row0 = blockIdx.x * MLP_ROWS;
+
+    if (tid < MLP_ROWS) {
+        const int row = row0 + tid;
+        double f[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (row < a.rows) {
+            double s, i, r, d, v, cap;
+            int32_t t, tmax;
+            if (a.st) {
+                const int e = row / a.n, c = row % a.n;
+                const size_t idx = (size_t)e * a.npad + c;
+                s = (double)a.st[0 * a.plane + idx]; i = (double)a.st[1 * a.plane + idx];
+                r = (double)a.st[2 * a.plane + idx]; d = (double)a.st[3 * a.plane + idx];
+                v = (double)a.st[4 * a.plane + idx];
+                cap = a.cap[idx]; t = a.tcur[idx]; tmax = a.state_t_max;
+            } else {
+                const epi_state& st = a.states[row];
+                s = st.s; i = st.i; r = st.r; d = st.d; v = st.v; cap = st.hosp_cap; t = st.t; tmax = st.t_max;
+            }
+            const double N = fmax(1.0, s + i + r + d);
+            f[0] = s / N; f[1] = i / N; f[2] = r / N; f[3] = d / N; f[4] = v / N;
+            f[5] = i / fmax(1.0, cap);
+            f[6] = (double)t / (double)(tmax > 1 ? tmax : 1);
+        }
+        for (int k = 0; k < 7; ++k) sh_x[tid][k] = f[k];
+    }
+    __syncthreads();
+    if (tid < H) {
+        double w[7];
+        for (int k = 0; k < 7; ++k) w[k] = a.W1[tid * 7 + k];
+        const double b = a.b1 ? a.b1[tid] : 0.0;
+        for (int r = 0; r < MLP_ROWS; ++r) {
+            double acc = w[0] * sh_x[r][0];
+            for (int k = 1; k < 7; ++k) acc = acc + w[k] * sh_x[r][k];
+            const double z = acc + b;
+            sh_h1[r][tid] = z > 0 ? z : 0.0;
+        }
+    }
+    __syncthreads();
+    if (tid < H) {
+        double acc[MLP_ROWS];
+        {
+            const double w = a.W2T[tid];
+#pragma unroll
+            for (int r = 0; r < MLP_ROWS; ++r) acc[r] = w * sh_h1[r][0];
+        }
+        for (int k = 1; k < H; ++k) {
+            const double w = a.W2T[(size_t)k * H + tid];
+#pragma unroll
+            for (int r = 0; r < MLP_ROWS; ++r) acc[r] = acc[r] + w * sh_h1[r][k];
+        }
+        const double b = a.b2 ? a.b2[tid] : 0.0;
+#pragma unroll
+        for (int r = 0; r < MLP_ROWS; ++r) {
+            const double z = acc[r] + b;
+            sh_h2[r][tid] = z > 0 ? z : 0.0;
+        }
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 3, o = tid & 7;  // 16 rows x 8 outputs = 128 threads
+        double acc = a.W3[o * H] * sh_h2[r][0];
+        for (int k = 1; k < H; ++k) acc = acc + a.W3[o * H + k] * sh_h2[r][k];
+        double y = acc + (a.b3 ? a.b3[o] : 0.0);
+        if (isfinite(a.clip_q)) y = fmax(-a.clip_q, fmin(a.clip_q, y));
+        sh_y[r][o] = y;
+    }
+    __syncthreads();
+    if (tid < MLP_ROWS) {
+        const int row = row0 + tid;
+        if (row < a.rows) {
+            int best = 0;
+            for (int o = 1; o < 8; ++o)
+                if (sh_y[tid][o] > sh_y[tid][best]) best = o;
+            if (a.act_episode) {
+                const int e = row / a.n, c = row % a.n;
+                a.act_episode[(size_t)e * a.npad + c] = (int8_t)best;
+            }
+            if (a.act_out) a.act_out[row] = best;
+            if (a.q_out)
+                for (int o = 0; o < 8; ++o) a.q_out[(size_t)row * 8 + o] = sh_y[tid][o];
+        }
+    }
+}
+
+hipError_t launch_mlp(const MlpArgs& a, hipStream_t s) {
+    if (a.rows <= 0) return hipSuccess;
+    if (a.hidden < 1 || a.hidden > MLP_MAXH) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mlp_greedy_kernel, dim3((unsigned)((a.rows + MLP_ROWS - 1) / MLP_ROWS)), dim3(128), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// EpidemicEnv.allocateInt for `batch` independent rows of n <= 1024 weights: one wave per row.
+// The sequential weight sum (weights.sum, env.scala:242) is done by lane 0 through LDS so that
+// it rounds like the reference.
+// ---------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(64) void alloc_batch_kernel(const AllocBatchArgs a) {
+    __shared__ double sh_q[R * 64];
+    __shared__ double sh_sum;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = a.n;
+    const double* w = a.w + (size_t)b * n;
+    for (int j = lane; j < R * 64; j += 64) sh_q[j] = j < n ? w[j] : 0.0;
+    __syncthreads();
+    if (lane == 0) {
+        double sum = n > 0 ? sh_q[0] : 0.0;
+        for (int j = 1; j < n; ++j) sum = sum + sh_q[j];
+        sh_sum = sum;
+    }
+    __syncthreads();
+    const double sum = sh_sum;
+    const int32_t total = a.totals[b];
+    uint32_t acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0u;
+    if (total > 0 && sum > 0.0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) sh_q[r * 64 + lane] = sh_q[r * 64 + lane] / sum;
+        __syncthreads();
+        apportion_row<R>(total, n, -1, sh_q, acc, lane);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int j = r * 64 + lane;
+        if (j < n) a.out[(size_t)b * n + j] = (int32_t)acc[r];
+    }
+}
+
+hipError_t launch_alloc_batch(const AllocBatchArgs& a, hipStream_t s) {
+    if (a.batch <= 0 || a.n <= 0) return hipSuccess;
+    const dim3 grid((unsigned)a.batch), block(64);
+    switch (dense_slots_for(a.n)) {
+        case 1: hipLaunchKernelGGL(alloc_batch_kernel<1>, grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL(alloc_batch_kernel<2>, grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL(alloc_batch_kernel<4>, grid, block, 0, s, a); break;
+        case 8: hipLaunchKernelGGL(alloc_batch_kernel<8>, grid, block, 0, s, a); break;
+        case 16: hipLaunchKernelGGL(alloc_batch_kernel<16>, grid, block, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// EpidemicEnv.step for a batch of independent rows (env.scala:58-140), reward and done included.
+// ---------------------------------------------------------------------------------------------
+__global__ void env_batch_kernel(const EnvBatchArgs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.batch) return;
+    const epi_state st = a.in[b];
+    const StepConsts c = make_step_consts(a.env[b], a.prof[b]);
+    int act = a.action[b];
+    act = act < 0 ? 0 : (act > 7 ? 7 : act);
+    const int32_t s0 = round_count(st.s), i0 = round_count(st.i), r0 = round_count(st.r), d0 = round_count(st.d),
+                  v0 = round_count(st.v);
+    const LocalOut o = local_step(c, s0, i0, r0, d0, v0, st.hosp_cap, act, a.gauss[b]);
+    epi_state nx = st;
+    nx.s = (double)o.s; nx.i = (double)o.i; nx.r = (double)o.r; nx.d = (double)o.d; nx.v = (double)o.v;
+    nx.hosp_cap = o.cap;
+    nx.t = (int32_t)((uint32_t)st.t + 1u);
+    a.out[b] = nx;
+    if (a.reward) {
+        const RewardConsts rc = make_reward_consts(a.env[b], a.prof[b]);
+        a.reward[b] = reward_of(rc, st.i, st.d, o, act);
+    }
+    if (a.done) {
+        const double nn = fmax(1.0, nx.s + nx.i + nx.r + nx.d);
+        a.done[b] = (nx.t >= nx.t_max) || (nx.i / nn < 1e-5) || (nx.d / nn > 0.02);
+    }
+}
+
+hipError_t launch_env_batch(const EnvBatchArgs& a, hipStream_t s) {
+    if (a.batch <= 0) return hipSuccess;
+    hipLaunchKernelGGL(env_batch_kernel, dim3((unsigned)((a.batch + 127) / 128)), dim3(128), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace epi

@@ -1,0 +1,106 @@
+// Kernel argument blocks and launch entry points shared by the kernels (epi_kernels.hip)
+// and the host engine (epi_capi.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "epi_device.hpp"
+
+namespace epi {
+
+constexpr int kMaxDenseR = 16;               // register slots per lane in the dense row kernel
+constexpr int kMaxDenseN = kMaxDenseR * 64;  // widest dense row held in one wave's registers
+
+// Indices into the per-country constant table cst[k][npad] (StepConsts minus beta0).
+enum { CST_GAMMA = 0, CST_IFR0, CST_CNOISE, CST_EFF1, CST_EFF2, CST_EFF3, CST_SURGE, CST_VAX6, CST_VAX7, CST_COUNT };
+
+// One launch of the fused dense episode kernel: steps [t_begin, t_end) of `count` episodes, one
+// workgroup per episode, npad threads (one per padded country, one wave per 64).
+struct EpisodeArgs {
+    int n, npad, count;
+    int seed_idx, n_travel;  // travel variant of the seed row: (g_begin + e) % n_travel; < 0 = none
+    int g_begin;             // flat grid index of episode 0 (beta index = g / n_travel)
+    int t_begin, t_end;
+    int step_t_max;          // the tMax argument of stepOne (WorldToy.scala:135)
+    int validate;
+    const double* q;         // [n][npad]  w_ij / sumW_i, diagonal and padding 0
+    const double* sumw;      // [npad]     max(0, sum_j wRow_j)  (WorldToy.scala:114)
+    const double* qseed;     // [n_travel][npad] seed-row variants (ToyConn.scaleRow per travel scale)
+    const double* sumw_seed; // [n_travel]
+    const double* beta0;     // [n_beta][npad] or [1][npad]
+    int beta_rows;           // rows in beta0; episode uses row min(g / n_travel, beta_rows-1)
+    const double* cst;       // [CST_COUNT][npad]
+    const int8_t* actions;   // [.][npad] shared per-step actions, indexed by t - act_t0
+    int act_t0;
+    const int8_t* act_episode;  // optional [count][npad]: actions of every episode for step t_begin
+    const double* noise;     // [.][npad] shared per-step Gaussian draws, indexed by t - noise_t0 ...
+    int noise_t0;
+    const double* noise_episode;  // optional [count][npad]: draws of every episode for step t_begin
+    int32_t* st;             // [5][count][npad] s,i,r,d,v
+    double* cap;             // [count][npad]
+    int32_t* tcur;           // [count][npad] State.t
+    int32_t* arrival;        // [count][npad] first step index with I >= 10, or -1
+    int32_t* peak;           // [count][npad] running max of I
+    int32_t* err;            // [count][4] code, node, t, -
+    // optional outputs of the world API
+    const RewardConsts* rwd; // [npad] or NULL
+    double* reward_out;      // [count][npad]
+    int32_t* flow_s;         // [count][npad] movedS of the last step (WorldToy.scala:106-126)
+    int32_t* flow_i;
+};
+
+struct InitArgs {
+    int n, npad, count, seed_idx;
+    const int32_t* pop;  // [npad]
+    double base_cap;
+    int32_t r0, d0, v0, t0;
+    int32_t* st; double* cap; int32_t* tcur; int32_t* arrival; int32_t* peak; int32_t* err;
+};
+
+struct LossArgs {
+    int n, npad, count, steps;
+    const int32_t* arrival; const int32_t* peak;
+    const double* t_arrive; const uint8_t* has_arrive; const double* t_peak; const uint8_t* has_peak;
+    double* loss; int32_t* arrival_out; double* peak_out;  // arrival_out/peak_out [count][n] optional
+};
+
+struct MlpArgs {
+    int rows;          // (episode, country) pairs, row = e * n + c
+    int n, npad, hidden;
+    int state_t_max;
+    const int32_t* st; const double* cap; const int32_t* tcur; size_t plane;  // episode state layout
+    const epi_state* states;  // alternative input: rows states (AoS), used when st == NULL
+    const double* W1; const double* b1;   // [h][7]
+    const double* W2T; const double* b2;  // [h(k)][h(u)] transposed
+    const double* W3; const double* b3;   // [8][h]
+    double clip_q;
+    int8_t* act_episode;  // [count][npad] (when st != NULL)
+    int32_t* act_out;     // [rows] optional
+    double* q_out;        // [rows][8] optional
+};
+
+struct AllocBatchArgs {
+    int n, npad, batch;
+    const int32_t* totals; const double* w; int32_t* out;
+};
+
+struct EnvBatchArgs {
+    int batch;
+    const epi_env_params* env; const epi_profile* prof; const epi_state* in; const int32_t* action;
+    const double* gauss; epi_state* out; double* reward; uint8_t* done;
+};
+
+hipError_t launch_episode(const EpisodeArgs& a, hipStream_t s);
+hipError_t launch_init(const InitArgs& a, hipStream_t s);
+hipError_t launch_loss(const LossArgs& a, hipStream_t s);
+hipError_t launch_mlp(const MlpArgs& a, hipStream_t s);
+hipError_t launch_alloc_batch(const AllocBatchArgs& a, hipStream_t s);
+hipError_t launch_env_batch(const EnvBatchArgs& a, hipStream_t s);
+
+inline int dense_slots_for(int n) {  // smallest supported R with 64*R >= n
+    int r = 1;
+    while (r * 64 < n) r *= 2;
+    return r;
+}
+
+}  // namespace epi

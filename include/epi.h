@@ -1,0 +1,197 @@
+/*
+ * epi.h -- C ABI of the MI355X engine for the metapopulation step and the
+ * beta x travel calibration sweep.
+ *
+ * The reference has no FFI on this path: its public Scala API *is* the boundary.
+ * Each entry point below names the reference function(s) it stands in for
+ * (paths relative to the reference tree, src/main/scala/epidemic/).  A JVM shim
+ * keeps the Scala signatures and forwards to these functions through JNI or the
+ * Panama FFM linker.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every array is caller-owned and is not
+ *     retained after the call returns, except where a handle documents otherwise
+ *   - every function returns an epi_status (0 = ok); epi_last_error() gives the
+ *     message of the calling thread's last failure
+ *   - all compute runs on the GPU; there is no CPU fallback.  When no HIP device
+ *     is usable the functions return EPI_ERR_DEVICE
+ *   - invariant violations that make the reference throw
+ *     IllegalArgumentException (WorldToy.scala:94,144; Validation.scala:7-10) are
+ *     reported as EPI_ERR_LOCAL_MASS / EPI_ERR_WORLD_MASS / EPI_ERR_ASSERT_STATE
+ *     with the reference's message text in epi_last_error()
+ */
+#ifndef EPI_H_
+#define EPI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum epi_status {
+    EPI_OK = 0,
+    EPI_ERR_BAD_ARGUMENT = 1,
+    EPI_ERR_DEVICE = 2,
+    EPI_ERR_LOCAL_MASS = 3,   /* "mass not conserved (local)"           WorldToy.scala:94  */
+    EPI_ERR_WORLD_MASS = 4,   /* "global mass changed during mobility"  WorldToy.scala:144 */
+    EPI_ERR_ASSERT_STATE = 5, /* Validation.assertState                 Validation.scala:6-11 */
+    EPI_ERR_INT_RANGE = 6     /* a compartment left the Int range the reference computes in */
+} epi_status;
+
+/* Geo.Country fields read by EpidemicEnv (Geo.scala:4-21; env.scala:59-101,142-234). */
+typedef struct epi_profile {
+    double beta_mul, ifr_mul, noise, population_density, gdp_per_capita, healthcare_capacity, age_elderly,
+        connectivity, econ_resilience;
+} epi_profile;
+
+/* EpidemicEnv constructor arguments (env.scala:32-41); the seed is passed separately. */
+typedef struct epi_env_params {
+    double base_beta, base_gamma, base_ifr, noise, reward_clip, risk_factor;
+} epi_env_params;
+
+/* State (env.scala:22-25). */
+typedef struct epi_state {
+    double s, i, r, d, v, hosp_cap;
+    int32_t t, t_max, seed, pad_;
+} epi_state;
+
+/* HyperParams fields the path reads (config.scala:3-21). */
+typedef struct epi_hyper {
+    double epsilon_start, epsilon_end;
+    int32_t epsilon_decay_steps, hidden;
+    double clip_q, reward_clip;
+    int32_t batch_size, learn_every;
+} epi_hyper;
+
+int32_t epi_version(void);
+/* Copies the calling thread's last error message (NUL-terminated) and returns its length. */
+int32_t epi_last_error(char *buf, size_t cap);
+/* Number of usable HIP devices (0 when none). */
+int32_t epi_device_count(void);
+
+/* ---- EpidemicEnv.allocateInt (env.scala:241-254) ------------------------------------------- */
+/* out[n] = largest-remainder split of `total` over weights w[n]. */
+int32_t epi_alloc_int(int32_t total, const double *w, int32_t n, int32_t *out);
+/* B independent splits in one launch: totals[B], w[B][n] row-major, out[B][n]. */
+int32_t epi_alloc_int_batch(const int32_t *totals, const double *w, int32_t n, int32_t batch, int32_t *out);
+
+/* ---- EpidemicEnv.step incl. reward and done (env.scala:58-234) -------------------------------- */
+/* B independent (env, state, action) rows.  gauss[b] is the value rnd.nextGaussian() returns at
+ * env.scala:91 for that row.  Compartments must be finite; they are rounded as env.scala:81-85 does. */
+int32_t epi_env_step_batch(const epi_env_params *env, const epi_profile *prof, const epi_state *in,
+                           const int32_t *action, const double *gauss, epi_state *out, double *reward,
+                           uint8_t *done, int32_t batch);
+
+/* ---- ToyConn.scaleRow (ToyConn.scala:58-70) --------------------------------------------------- */
+/* out[n*n] = copy of W with row `row` scaled by factor and its sum capped at 0.2 (host arithmetic,
+ * same operation order). */
+int32_t epi_scale_row(const double *W, int32_t n, int32_t row, double factor, double *out);
+
+/* ---- JVM-compatible streams (scala.util.Random at env.scala:42,91; DDQNAgent.scala:14-32;
+ *      MLP.scala:5-9) ------------------------------------------------------------------------- */
+int32_t epi_java_gaussians(int64_t seed, int32_t n, double *out);
+/* Action stream of a fresh DDQNAgent for `steps` act() calls: 0..7, or -1 where it takes argmax Q. */
+int32_t epi_agent_actions(const epi_hyper *hp, int32_t steps, int32_t *out);
+/* Untrained network weights: W1[h*in], W2[h*h], W3[out*h]. */
+int32_t epi_mlp_init(int32_t n_in, int32_t hidden, int32_t n_out, double *W1, double *W2, double *W3);
+/* DDQNAgent.actGreedy / MLP.predict (DDQNAgent.scala:22-23, MLP.scala:15-22) for B states with the
+ * given weights (biases may be NULL = zero): q[B][n_out] clamped to +-clip_q and the first argmax. */
+int32_t epi_mlp_greedy_batch(const epi_state *states, int32_t batch, int32_t hidden, const double *W1,
+                             const double *b1, const double *W2, const double *b2, const double *W3,
+                             const double *b3, double clip_q, double *q, int32_t *action);
+
+/* ---- Calibrate.gridSurface / rollout (Calibrate.scala:19-116) over WorldToy.stepOne
+ *      (WorldToy.scala:24-32,83-145), Validation.arrivalTime/peakI (Validation.scala:15-22) ------ */
+typedef struct epi_grid_desc {
+    int32_t n;              /* countries (ToyConn.C generalised to an input list) */
+    const int32_t *pop;     /* [n] */
+    const double *conn;     /* dense [n*n] row-major connection matrix W, or NULL when CSR is given */
+    const int32_t *csr_rowptr; /* [n+1]  CSR form of W (structural zeros = weight 0) */
+    const int32_t *csr_col;    /* [nnz]  strictly ascending inside a row */
+    const double *csr_val;     /* [nnz] */
+    int32_t seed_idx;       /* seedIdx */
+    int32_t heterogeneous;  /* Calibrate.scala:34-54 */
+    epi_state base;         /* hospCap, r, d, v, t, tMax are read (WorldToy.scala:28-32) */
+    const epi_profile *prof; /* [n] country profiles (read when heterogeneous != 0) */
+    epi_hyper hp;
+    int32_t steps;          /* cfg.stepsPerEpoch */
+    int32_t n_beta;
+    const double *betas;    /* [n_beta]   betaGrid (outer loop) */
+    int32_t n_travel;
+    const double *travel;   /* [n_travel] travelScales (inner loop) */
+    const double *t_arrive; /* [n] Targets.tArrive values, read where has_arrive != 0 */
+    const uint8_t *has_arrive;
+    const double *t_peak;   /* [n] Targets.peakI */
+    const uint8_t *has_peak;
+    int32_t device;         /* HIP device ordinal */
+    int32_t pad_;
+} epi_grid_desc;
+
+typedef struct epi_grid epi_grid;
+
+/* Uploads the graph and builds every per-sweep table on `desc->device`.  Nothing in `desc` is
+ * retained.  Returns NULL on failure (see epi_last_error). */
+epi_grid *epi_grid_create(const epi_grid_desc *desc);
+/* Runs grid points [g_begin, g_begin+g_count) (flat index g = i_beta*n_travel + i_travel, the
+ * reference's loop order).  loss[g_count]; arrival[g_count][n] and peak[g_count][n] may be NULL.
+ * With out_on_device != 0 the three pointers are device memory on the handle's device, the work is
+ * only enqueued on `stream` (a hipStream_t, NULL = default stream) and the status of the run is
+ * collected by epi_grid_status().  Otherwise they are host memory and the call is synchronous. */
+int32_t epi_grid_run(epi_grid *g, int32_t g_begin, int32_t g_count, double *loss, int32_t *arrival, double *peak,
+                     int32_t out_on_device, void *stream);
+/* Waits for the last enqueued run and returns its status (first failing grid point wins). */
+int32_t epi_grid_status(epi_grid *g);
+int32_t epi_grid_destroy(epi_grid *g);
+/* First minimum in flat order with strict '<' starting from Double.MaxValue (Calibrate.scala:96,112). */
+int32_t epi_grid_argmin(const double *loss, int32_t count, int32_t *best_idx, double *best_loss);
+/* gridSurface in one call on one device: loss[n_beta*n_travel] beta-major; arrival/peak optional. */
+int32_t epi_calibrate_grid(const epi_grid_desc *desc, double *loss, int32_t *arrival, double *peak,
+                           int32_t *best_idx, double *best_loss);
+
+/* ---- WorldToy (WorldToy.scala:11-235): batched worlds stepped on the device ------------------- */
+typedef struct epi_world_desc {
+    int32_t n;
+    int32_t batch;          /* independent world instances sharing graph and env parameters */
+    const int32_t *pop;     /* [n] */
+    const double *conn;     /* dense [n*n] or NULL */
+    const int32_t *csr_rowptr;
+    const int32_t *csr_col;
+    const double *csr_val;
+    int32_t seed_idx;
+    int32_t validate;       /* WorldToy validate flag: mass checks on */
+    epi_state base;
+    const epi_env_params *env; /* [n] one EpidemicEnv per country (makeEnvFor) */
+    const epi_profile *prof;   /* [n] */
+    const int32_t *env_seeds;  /* [n] Random seeds of the envs (env.scala:42); instance b uses seed+b*0 (same streams) */
+    epi_hyper hp;
+    int32_t device;
+    int32_t pad_;
+} epi_world_desc;
+
+typedef struct epi_world epi_world;
+
+epi_world *epi_world_create(const epi_world_desc *desc);
+/* One WorldToy.stepOne (:83-145) for every instance with caller-chosen actions[batch][n].
+ * gauss[batch][n] supplies the env noise draws; NULL = the engine's own JVM-compatible streams
+ * (one per country, shared by all instances, exactly what `batch` fresh copies of the reference
+ * world would draw).  out_states[batch][n] / out_rewards[batch][n] may be NULL. */
+int32_t epi_world_step(epi_world *w, const int32_t *actions, const double *gauss, int32_t t_max,
+                       epi_state *out_states, double *out_rewards);
+/* WorldToy.stepOneGreedy (:172-235): actions = argmax Q(features) with the weights set below. */
+int32_t epi_world_step_greedy(epi_world *w, const double *gauss, int32_t t_max, epi_state *out_states,
+                              double *out_rewards, int32_t *out_actions);
+int32_t epi_world_set_mlp(epi_world *w, int32_t hidden, const double *W1, const double *b1, const double *W2,
+                          const double *b2, const double *W3, const double *b3, double clip_q);
+int32_t epi_world_get_states(epi_world *w, epi_state *out);       /* snapshotStates :75 */
+int32_t epi_world_set_states(epi_world *w, const epi_state *in);  /* restoreStates  :76 */
+int32_t epi_world_reset(epi_world *w);                            /* resetToInitial :77 */
+/* Net S and I flows of the last step, movedS/movedI[batch][n] (WorldToy.scala:106-126). */
+int32_t epi_world_last_flows(epi_world *w, int32_t *moved_s, int32_t *moved_i);
+int32_t epi_world_destroy(epi_world *w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPI_H_ */

@@ -1,0 +1,315 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the same seeded
+inputs.  Bar: bit-exact for every integer (allocations, compartments, flows, arrival, peak, actions);
+fp64 losses and rewards within 1e-12 relative (rewards are in fact compared bit for bit)."""
+import numpy as np
+import pytest
+
+from oracle import oracle_lib as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def epi():
+    import epidemicsimulator_amd as E
+    assert E.lib().epi_device_count() >= 1, "no HIP device: GPU tests must run on the MI355X box"
+    return E
+
+
+# ---------------------------------------------------------------- allocateInt (env.scala:241-254)
+def test_alloc_int_known_answers(epi):
+    A = epi.EpidemicEnv.allocate_int
+    assert A(10, [.5, .3, .2]) == [5, 3, 2]
+    assert A(10, [1, 1, 1]) == [4, 3, 3]
+    assert A(7, [0, 2, 1, 1]) == [0, 3, 2, 2]
+    assert A(1, [.25] * 4) == [1, 0, 0, 0]
+    assert A(5, [0, 0, 0]) == [0, 0, 0]
+    assert A(0, [1, 2, 3]) == [0, 0, 0]
+    assert A(-3, [1, 2, 3]) == [0, 0, 0]
+
+
+@pytest.mark.parametrize("n", [1, 3, 6, 63, 64, 65, 200, 511, 1000, 1024])
+def test_alloc_int_random_rows(epi, n):
+    rng = np.random.default_rng(1000 + n)
+    B = 48
+    w = rng.random((B, n)) ** 3
+    w[rng.random((B, n)) < 0.1] = 0.0
+    w[3] = 1.0                       # all fractions identical: index-order ties
+    w[4] = 0.0                       # zero sum
+    w[5] = np.round(w[5] * 4) / 4    # many exact ties
+    w[6, : n // 2] = 0.0
+    totals = rng.integers(0, 2_000_000_000, B).astype(np.int32)
+    totals[:12] = [0, 1, 2, 3, 5, 7, n, n + 1, max(n - 1, 0), 2 * n + 1, 17, 1_999_999_999]
+    totals[3], totals[5] = 5 * n + n // 3, 123457
+    got = epi.EpidemicEnv.allocate_int_batch(totals, w)
+    for b in range(B):
+        np.testing.assert_array_equal(got[b], O.alloc_int(totals[b], w[b]), err_msg="row %d total %d" % (b, totals[b]))
+
+
+def test_alloc_int_small_totals_heavy_tail(epi):
+    rng = np.random.default_rng(7)
+    n, B = 1000, 64
+    w = np.exp(rng.normal(0, 3.0, (B, n)))
+    totals = rng.integers(1, 40, B).astype(np.int32)
+    got = epi.EpidemicEnv.allocate_int_batch(totals, w)
+    for b in range(B):
+        np.testing.assert_array_equal(got[b], O.alloc_int(totals[b], w[b]))
+        assert got[b].sum() == totals[b]
+
+
+def test_alloc_int_rejects_bad_weights(epi):
+    with pytest.raises(epi.EpiError):
+        epi.EpidemicEnv.allocate_int(5, [1.0, float("nan")])
+    with pytest.raises(epi.EpiError):
+        epi.EpidemicEnv.allocate_int(5, [1.0, -0.5])
+
+
+# ---------------------------------------------------------------- EpidemicEnv.step (env.scala:58-234)
+def test_env_step_batch_matches_oracle(epi):
+    rng = np.random.default_rng(11)
+    B = 512
+    countries, _ = __import__("epidemicsimulator_amd.synth", fromlist=["x"]).make_countries(B, 99)
+    envs, states, acts, gauss = [], [], [], []
+    for b in range(B):
+        c = countries[b]
+        envs.append(epi.EpidemicEnv(0.15 + 0.4 * rng.random(), 0.12, 0.004 + 0.02 * rng.random(), 0.05 + 0.1 * rng.random(),
+                                    5.0, rng.random() * (b % 3 == 0), c.name, 42, profile=c))
+        pop = int(c.pop)
+        i = int(rng.integers(0, max(2, pop // 50)))
+        r = int(rng.integers(0, pop // 10)); d = int(rng.integers(0, pop // 100)); v = int(rng.integers(0, pop // 10))
+        states.append(epi.State(pop - i, i, r, d, v, float(rng.choice([1.0, 50.0, 1e4, 1e6])), int(rng.integers(0, 50)), 50, 1))
+        acts.append(int(rng.integers(-1, 10)))
+        gauss.append(float(rng.normal()))
+    states[0] = epi.State(0, 0, 0, 0, 0, 1.0, 0, 10, 1)
+    states[1] = epi.State(10, 0, 0, 0, 0, 1.0, 9, 10, 1)
+    states[2] = epi.State(0.4, 2.5, 3.49, 0.5, 1.5, 7.0, 3, 10, 1)   # Math.round on non-integers
+    nxt, rew, done = epi.EpidemicEnv.step_batch(envs, states, acts, gauss)
+    for b in range(B):
+        o_next, o_r, o_done = O.env_step(O.EnvParams(*[getattr(envs[b]._c(), f[0]) for f in O.EnvParams._fields_]),
+                                         O.profiles_array([util.prof_dict(envs[b].country_profile)])[0],
+                                         util.oracle_state(states[b]), acts[b], gauss[b])
+        g = nxt[b]
+        assert (g.s, g.i, g.r, g.d, g.v, g.hosp_cap, g.t) == o_next.tup(), "row %d" % b
+        assert rew[b] == o_r, "reward row %d: %r vs %r" % (b, rew[b], o_r)
+        assert bool(done[b]) == o_done
+
+
+def test_heterogeneity_spec(epi):
+    """HeterogeneitySpec.scala:18-29: different multipliers give a different next I."""
+    cn = next(c for c in epi.ToyConn.C if c.name == "China")
+    jp = next(c for c in epi.ToyConn.C if c.name == "Japan")
+    s0 = epi.State(1_000_000, 1_000, 0, 0, 0, 10_000, 0, 10, 1)
+    mk = lambda c: epi.EpidemicEnv(0.26 * c.beta_mul, 0.12, 0.008 * c.ifr_mul, c.noise, 5.0)
+    a, _, _ = mk(cn).step(s0, epi.Action.from_id(0))
+    b, _, _ = mk(jp).step(s0, epi.Action.from_id(0))
+    assert a.i != b.i
+
+
+# ---------------------------------------------------------------- MLP.predict / actGreedy
+def test_mlp_greedy_matches_oracle(epi):
+    rng = np.random.default_rng(5)
+    W = epi.mlp_init(128)
+    oW = O.mlp_weights()
+    for a, b in zip(W, oW):
+        np.testing.assert_array_equal(a, b)
+    states = []
+    for _ in range(100):
+        pop = int(rng.integers(1000, 10**9))
+        i = int(rng.integers(0, pop // 3)); r = int(rng.integers(0, pop // 3))
+        states.append(epi.State(pop - i - r, i, r, int(rng.integers(0, 1000)), int(rng.integers(0, 1000)),
+                                float(rng.choice([1.0, 1e4, 3e5])), int(rng.integers(0, 300)), 300, 1))
+    q, act = epi.mlp_greedy(states, W, 10.0)
+    for k, st in enumerate(states):
+        want = O.mlp_predict(np.array(st.features()), 10.0)
+        np.testing.assert_array_equal(q[k], want)
+        assert act[k] == int(np.argmax(want))
+
+
+# ---------------------------------------------------------------- WorldToy.stepOne (WorldToy.scala:83-145)
+def _world_pair(epi, countries, conn, batch, seed=3):
+    n = len(countries)
+    rng = np.random.default_rng(seed)
+    base = epi.State(0, 0, 0, 0, 0, 10_000, 0, 120, 42)
+    envs = [epi.EpidemicEnv(0.2 + 0.2 * rng.random(), 0.12, 0.008, 0.03 + 0.05 * rng.random(), 5.0, 0.3 * (k % 2),
+                            c.name, 100 + k, profile=c) for k, c in enumerate(countries)]
+    it = iter(envs)
+    w = epi.WorldToy(epi.HyperParams(), base, 0, conn, make_env_for=lambda name, pop: next(it), validate=True,
+                     countries=countries, batch=batch)
+    ow = O.World([c.pop for c in countries], util.dense_of(conn, n), 0, util.oracle_state(base),
+                 [O.EnvParams(e.base_beta, e.base_gamma, e.base_ifr, e.noise, e.reward_clip, e.risk_factor) for e in envs],
+                 [util.prof_dict(e.country_profile) for e in envs], [e.seed for e in envs], validate=True)
+    return w, ow, rng
+
+
+@pytest.mark.parametrize("n", [6, 70, 200])
+def test_world_step_given_actions(epi, n):
+    from epidemicsimulator_amd import synth
+    if n == 6:
+        countries, conn = list(epi.ToyConn.C), epi.ToyConn.W
+    else:
+        countries, xy = synth.make_countries(n, 31 + n)
+        conn = synth.gravity_dense(countries, xy)
+    w, ow, rng = _world_pair(epi, countries, conn, batch=1)
+    for step in range(25):
+        acts = rng.integers(0, 8, n)
+        gauss = rng.normal(size=n)
+        states, rewards = w.step_actions([acts], [gauss], 120)
+        o_r, o_ms, o_mi = ow.step_given(acts, gauss, 120)
+        o_states = ow.states()
+        assert ow.error()[0] == 0
+        for c in range(n):
+            g = states[0][c]
+            assert (g.s, g.i, g.r, g.d, g.v, g.hosp_cap, g.t) == o_states[c].tup(), "step %d country %d" % (step, c)
+        np.testing.assert_array_equal(rewards[0], o_r)
+        ms, mi = w.last_flows()
+        np.testing.assert_array_equal(ms[0], o_ms)
+        np.testing.assert_array_equal(mi[0], o_mi)
+        assert int(ms.sum()) + int(mi.sum()) == 0      # MobilitySpec.scala:61-62
+
+
+def test_world_batch_instances_are_independent(epi):
+    from epidemicsimulator_amd import synth
+    countries, xy = synth.make_countries(40, 5)
+    conn = synth.gravity_dense(countries, xy)
+    B = 5
+    w, ow, rng = _world_pair(epi, countries, conn, batch=B)
+    acts = rng.integers(0, 8, (B, 40)); gauss = rng.normal(size=(B, 40))
+    states, rewards = w.step_actions(acts, gauss, 120)
+    for b in range(B):
+        ow.reset()
+        o_r, _, _ = ow.step_given(acts[b], gauss[b], 120)
+        o_states = ow.states()
+        for c in range(40):
+            g = states[b][c]
+            assert (g.s, g.i, g.r, g.d, g.v, g.hosp_cap, g.t) == o_states[c].tup()
+        np.testing.assert_array_equal(rewards[b], o_r)
+
+
+def test_world_step_one_and_greedy_follow_reference_streams(epi):
+    """stepOne / stepOneGreedy with the JVM-compatible agent and env streams (EvalDeterminismSpec.scala
+    inputs: base tMax=120, beta 0.26, noise 0.02), checked against the oracle's WorldToy."""
+    hp = epi.HyperParams(learn_every=2**31 - 1)
+    base = epi.State(0, 0, 0, 0, 0, 10_000, 0, 120, 42)
+    mk = lambda: epi.EpidemicEnv(0.26, 0.12, 0.008, 0.02, hp.reward_clip)
+    n = 6
+    env = O.EnvParams(0.26, 0.12, 0.008, 0.02, 5.0, 0.0)
+    dflt = util.prof_dict(epi.Geo.CountryProfiles.get_profile("Unknown"))
+    for greedy in (True, False):
+        w = epi.WorldToy(hp, base, 0, epi.ToyConn.W, make_env=mk, validate=False)
+        w2 = epi.WorldToy(hp, base, 0, epi.ToyConn.W, make_env=mk, validate=False)
+        ohp = O.default_hyper(); ohp.learn_every = 2**31 - 1
+        ow = O.World([c.pop for c in epi.ToyConn.C], epi.ToyConn.W, 0, util.oracle_state(base), [env] * n, [dflt] * n,
+                     [42] * n, hp=ohp, validate=False)
+        a_series, b_series = [], []
+        for k in range(100):
+            out = w.step_one_greedy(100) if greedy else w.step_one(100)
+            out2 = w2.step_one_greedy(100) if greedy else w2.step_one(100)
+            o_r = ow.step(100, greedy)
+            o_states = ow.states()
+            for c in range(n):
+                g = out[c][1]
+                assert (g.s, g.i, g.r, g.d, g.v, g.hosp_cap, g.t) == o_states[c].tup(), "step %d" % k
+                assert out[c][2] == o_r[c]
+            np.testing.assert_array_equal([nd.last_a for nd in w.nodes], ow.last_actions())
+            a_series.append(out[0][1].i); b_series.append(out2[0][1].i)
+        assert a_series == b_series       # EvalDeterminismSpec.scala:37-45
+
+
+# ---------------------------------------------------------------- Calibrate.gridSurface
+def test_grid_toy_default_config(epi):
+    """Configuration 1: the toy country set, 4x5 grid, 300 steps, heterogeneous, fallback targets
+    (App.scala:97-107) -- every arrival/peak bit-exact, losses within 1e-12."""
+    from epidemicsimulator_amd import synth
+    wl = synth.workload("c1")
+    base = synth.base_state(300)
+    got = util.engine_grid(wl, base)
+    want = util.oracle_grid(wl, base)
+    util.assert_grid_equal(got, want)
+
+
+def test_grid_calibration_spec(epi):
+    """CalibrationSpec.scala:6-16: empty targets, homogeneous, 60 steps: rows non-empty, loss exactly 0."""
+    hp, cfg = epi.HyperParams(), epi.TrainConfig(epochs=1, steps_per_epoch=60)
+    base = epi.State(1_000_000, 0, 0, 0, 0, 10_000, 0, 60, 3)
+    rows, (best_loss, best) = epi.Calibrate.grid_surface(hp, cfg, base, 0, epi.Calibrate.Targets({}, {}), [0.24, 0.26],
+                                                         [0.8, 1.0], validate=False, heterogeneous=False)
+    assert len(rows) == 4 and all(r[2] == 0.0 for r in rows)
+    assert best_loss == 0.0 and best == (0.24, 0.8)
+
+
+@pytest.mark.parametrize("n,nb,nt,steps,het", [(70, 3, 4, 130, True), (200, 2, 3, 40, True), (200, 2, 2, 40, False),
+                                               (130, 2, 2, 30, True), (1000, 1, 2, 12, True)])
+def test_grid_synthetic_matches_oracle(epi, n, nb, nt, steps, het):
+    from epidemicsimulator_amd import synth
+    wl = synth.small_workload(n, nb, nt, steps, seed=77 + n)
+    base = synth.base_state(steps)
+    got = util.engine_grid(wl, base, het)
+    want = util.oracle_grid(wl, base, het)
+    util.assert_grid_equal(got, want)
+
+
+def test_grid_slabs_equal_whole(epi):
+    """A grid run in slabs (the multi-GPU partition) gives the same surface as one run."""
+    from epidemicsimulator_amd import synth
+    wl = synth.small_workload(64, 4, 4, 25, seed=9)
+    base = synth.base_state(25)
+    eng = epi.GridEngine(epi.HyperParams(), 25, base, 0, [c.pop for c in wl["countries"]], wl["conn"], wl["profiles"],
+                         wl["betas"], wl["travel"], wl["t_arrive"], wl["t_peak"], True)
+    whole = eng.run()
+    parts = [eng.run(g0, 4) for g0 in range(0, 16, 4)]
+    np.testing.assert_array_equal(np.concatenate([p["loss"] for p in parts]), whole["loss"])
+    np.testing.assert_array_equal(np.concatenate([p["arrival"] for p in parts]), whole["arrival"])
+    eng.close()
+
+
+def test_grid_csr_input_equals_dense(epi):
+    from epidemicsimulator_amd import synth
+    countries, xy = synth.make_countries(300, 21)
+    csr = synth.gravity_csr(countries, xy, 21, mean_degree=6.0)
+    wl = synth.small_workload(300, 2, 2, 30, seed=21)
+    wl["countries"], wl["profiles"], wl["conn"] = countries, countries, csr
+    base = synth.base_state(30)
+    got = util.engine_grid(wl, base)
+    want = util.oracle_grid(wl, base)
+    util.assert_grid_equal(got, want)
+
+
+def test_grid_assert_state_failure(epi):
+    """Validation.assertState on the initial states (WorldToy.scala:53): base.r != 0 breaks the mass invariant."""
+    from epidemicsimulator_amd import synth
+    wl = synth.small_workload(8, 1, 1, 5)
+    base = synth.base_state(5).copy(r=3.0)
+    with pytest.raises(epi.IllegalArgumentException):
+        util.engine_grid(wl, base)
+
+
+def test_grid_full_size_properties(epi):
+    """Configuration 2 at full size (200 countries, 32x32, T=200) through size-independent properties:
+    arrival in [0, T], peak >= first-step I, finite losses, seed country arrives at step 0, and a sample
+    of grid points re-run as single-point slabs reproduces the surface bit for bit."""
+    from epidemicsimulator_amd import synth
+    wl = synth.workload("c2")
+    base = synth.base_state(wl["steps"])
+    eng = epi.GridEngine(epi.HyperParams(), wl["steps"], base, 0, [c.pop for c in wl["countries"]], wl["conn"],
+                         wl["profiles"], wl["betas"], wl["travel"], wl["t_arrive"], wl["t_peak"], True)
+    out = eng.run()
+    assert np.isfinite(out["loss"]).all() and (out["loss"] >= 0).all()
+    assert (out["arrival"] >= 0).all() and (out["arrival"] <= wl["steps"]).all()
+    assert (out["arrival"][:, 0] == 0).all()
+    assert (out["peak"] >= 0).all()
+    for g in (0, 517, 1023):
+        one = eng.run(g, 1)
+        assert one["loss"][0] == out["loss"][g]
+        np.testing.assert_array_equal(one["arrival"][0], out["arrival"][g])
+        np.testing.assert_array_equal(one["peak"][0], out["peak"][g])
+    eng.close()
+    # two grid points of the full-size configuration against the oracle
+    wl2 = dict(wl); wl2["betas"], wl2["travel"] = [wl["betas"][5]], [wl["travel"][3], wl["travel"][30]]
+    want = util.oracle_grid(wl2, base)
+    got = dict(loss=out["loss"][[5 * 32 + 3, 5 * 32 + 30]], arrival=out["arrival"][[5 * 32 + 3, 5 * 32 + 30]],
+               peak=out["peak"][[5 * 32 + 3, 5 * 32 + 30]])
+    assert want["err"] == 0
+    np.testing.assert_array_equal(got["arrival"], want["arrival"])
+    np.testing.assert_array_equal(got["peak"], want["peak"])
+    np.testing.assert_allclose(got["loss"], want["loss"], rtol=1e-12, atol=0)
