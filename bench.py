@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Calibration-sweep benchmark: country-steps/s over the whole beta x travel grid.
+
+  python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c1]
+
+One "step" is one pass of the hot path over the whole grid of the workload: every (beta, travel)
+point is one episode of T world steps over n countries, so a step processes G*n*T country-steps.
+Inputs (graph, tables, targets) are resident in HBM before the timed region starts.
+
+With N > 1 (launched by torch.distributed.run, one rank per GPU) the flat grid is cut into N
+contiguous slabs, one per rank; after its slab every rank takes part in one RCCL all-gather of the
+fp64 loss surface and then finds the first minimum.  Total work is fixed: "scaling": "strong".
+
+Rank 0 prints one JSON line.  `roofline` prices the episode kernel by its ALGORITHMIC bytes
+(8*n + 68 per country-step for dense graphs) over the kernel time measured with HIP events on the
+launch stream; `cpu_baseline` is the CPU oracle (a C restatement of the reference's Scala path) timed on
+a bounded sample of the same workload on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def algorithmic_bytes_per_country_step(n, conn):
+    if isinstance(conn, tuple):  # CSR: 12 B per stored edge + 8 B row-pointer pair + 68 B of state/noise/action
+        rp = conn[0]
+        return 12.0 * float(rp[-1]) / n + 8.0 + 68.0
+    return 8.0 * n + 68.0
+
+
+def cpu_baseline(wl, base, threads, seconds_target=15.0):
+    """Oracle timed on a bounded sample: `threads` grid points (one per thread), the first `steps`
+    steps of each, sized from a short probe so the leg takes about seconds_target."""
+    import numpy as np
+    from oracle import oracle_lib as O
+    from tests import util
+    O.build()
+    pops = [c.pop for c in wl["countries"]]
+    profs = [util.prof_dict(p) for p in wl["profiles"]]
+    W = util.dense_of(wl["conn"], len(pops))
+    nt = len(wl["travel"])
+    G = len(wl["betas"]) * nt
+
+    def run(g0, steps, out, k):
+        b = util.oracle_state(base)
+        b.t_max = steps
+        t = time.perf_counter()
+        done, _ = O.bench_points(pops, W, wl["seed_idx"], b, profs, steps, wl["betas"], wl["travel"], True, g0, 1)
+        out[k] = (done, time.perf_counter() - t)
+
+    probe = [None]
+    probe_steps = max(1, min(wl["steps"], 4))
+    run(0, probe_steps, probe, 0)
+    per_step = probe[0][1] / probe_steps
+    steps = int(max(1, min(wl["steps"], seconds_target / max(per_step, 1e-9))))
+    threads = max(1, min(threads, G))
+    res = [None] * threads
+    ths = [threading.Thread(target=run, args=((k * (G // threads)) % G, steps, res, k)) for k in range(threads)]
+    t0 = time.perf_counter()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    wall = time.perf_counter() - t0
+    total = sum(r[0] for r in res)
+    return {"value": total / wall, "unit": "country-steps/s", "cores": threads, "kind": "port",
+            "sample": "%d grid points x first %d of %d steps, one point per thread, %.1f s wall; single-thread probe %.0f country-steps/s"
+                      % (threads, steps, wl["steps"], wall, probe[0][0] / probe[0][1])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import epidemicsimulator_amd as E
+    from epidemicsimulator_amd import synth
+
+    wl = synth.workload(args.workload)
+    n, T = len(wl["countries"]), wl["steps"]
+    nb, nt = len(wl["betas"]), len(wl["travel"])
+    G = nb * nt
+    base = synth.base_state(T)
+    eng = E.GridEngine(E.HyperParams(), T, base, wl["seed_idx"], [c.pop for c in wl["countries"]], wl["conn"],
+                       wl["profiles"], wl["betas"], wl["travel"], wl["t_arrive"], wl["t_peak"], True, device=local_rank)
+
+    # contiguous beta-major slabs, padded so that the all-gather pieces have equal size
+    per = (G + world - 1) // world
+    g0 = min(G, rank * per)
+    cnt = max(0, min(G, g0 + per) - g0)
+    loss_local = torch.zeros(per, dtype=torch.float64, device="cuda")
+    loss_all = torch.zeros(per * world, dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def one_step():
+        if cnt > 0:
+            eng.enqueue(g0, cnt, loss_local.data_ptr(), stream)
+        if world > 1:
+            dist.all_gather_into_tensor(loss_all, loss_local)
+            surface = loss_all
+        else:
+            surface = loss_local
+        host = surface.cpu().numpy()  # 8*G bytes; the argmin is Calibrate.scala:112's strict '<' scan
+        return E.grid_argmin(host[:G])
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    eng.status()
+    eng.set_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    best = None
+    for _ in range(args.steps):
+        best = one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    eng.status()
+    k_ms, k_launches, k_cs = eng.kernel_time()
+    eng.set_timing(False)
+
+    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+
+    total_cs = float(G) * n * T * args.steps
+    value = total_cs / elapsed
+    bpcs = algorithmic_bytes_per_country_step(n, wl["conn"])
+    achieved = (k_cs * bpcs / (k_ms * 1e-3)) / 1e9 if k_ms > 0 else 0.0
+    out = {
+        "metric": "country-steps/sec (calibration grid, whole node)",
+        "value": value, "unit": "country-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s: %d countries, %dx%d beta x travel grid, %d-step episodes, %s" % (
+            wl["name"], n, nb, nt, T, "CSR graph" if isinstance(wl["conn"], tuple) else "dense graph"),
+            "grid_points": G, "country_steps_per_step": G * n * T,
+            "parallelism": "grid slabs of %d points per GPU + RCCL all-gather of the fp64 loss surface" % per if world > 1
+            else "single GPU", "best_idx": int(best[0]), "best_loss": float(best[1])},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "episode_dense_kernel", "launches": int(k_launches),
+                     "avg_launch_ms": k_ms / max(1, k_launches),
+                     "algorithmic_bytes_per_country_step": bpcs,
+                     "algorithmic_bytes_per_launch": k_cs * bpcs / max(1, k_launches),
+                     "note": "rank-0 kernel time from HIP events on the launch stream; bytes = (8n+68) per country-step"},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, base, args.cpu_threads)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -597,6 +597,15 @@ class GridEngine:
     def status(self):
         check(lib().epi_grid_status(self._h))
 
+    def set_timing(self, on: bool):
+        check(lib().epi_grid_set_timing(self._h, int(on)))
+
+    def kernel_time(self):
+        """(total ms, launches, country-steps) of the episode kernel since set_timing(True)."""
+        ms = C.c_double(0); k = C.c_int64(0); cs = C.c_int64(0)
+        check(lib().epi_grid_kernel_time(self._h, C.byref(ms), C.byref(k), C.byref(cs)))
+        return ms.value, k.value, cs.value
+
 
 def grid_argmin(loss) -> Tuple[int, float]:
     loss = f64(loss)

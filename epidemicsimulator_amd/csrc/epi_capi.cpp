@@ -285,6 +285,12 @@ struct epi_grid {
     DevBuf loss_tmp, arrival_tmp, peak_tmp;
     int last_count = 0, last_g_begin = 0;
     bool pending = false;
+    // optional timing of the episode kernel launches (HIP events on the launch stream)
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> open_events;
+    double kernel_ms = 0.0;
+    long long kernel_launches = 0;
+    long long kernel_country_steps = 0;
 };
 
 struct epi_world {
@@ -598,10 +604,67 @@ EPI_API epi_grid* epi_grid_create(const epi_grid_desc* desc) {
     return G.release();
 }
 
+static int32_t drain_events(epi_grid* g);
+
 EPI_API int32_t epi_grid_destroy(epi_grid* g) {
     if (!g) return EPI_OK;
     (void)hipSetDevice(g->device);
+    (void)drain_events(g);
     delete g;
+    return EPI_OK;
+}
+
+// Launches one segment of the episode kernel, bracketed by HIP events when timing is on.
+static int32_t timed_episode(epi_grid* g, const EpisodeArgs& ea, hipStream_t s) {
+    if (!g->timing) {
+        HIP_TRY(launch_episode(ea, s));
+        return EPI_OK;
+    }
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    HIP_TRY(hipEventRecord(a, s));
+    HIP_TRY(launch_episode(ea, s));
+    HIP_TRY(hipEventRecord(b, s));
+    g->open_events.emplace_back(a, b);
+    g->kernel_country_steps += (long long)ea.count * ea.n * (ea.t_end - ea.t_begin);
+    return EPI_OK;
+}
+
+static int32_t drain_events(epi_grid* g) {
+    for (auto& ev : g->open_events) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(ev.second));
+        HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+        g->kernel_ms += ms;
+        g->kernel_launches += 1;
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    g->open_events.clear();
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_grid_set_timing(epi_grid* g, int32_t on) {
+    if (!g) return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_set_timing: null handle");
+    HIP_TRY(hipSetDevice(g->device));
+    int32_t rc = drain_events(g);
+    if (rc) return rc;
+    g->timing = on != 0;
+    g->kernel_ms = 0.0;
+    g->kernel_launches = 0;
+    g->kernel_country_steps = 0;
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_grid_kernel_time(epi_grid* g, double* total_ms, int64_t* launches, int64_t* country_steps) {
+    if (!g) return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_kernel_time: null handle");
+    HIP_TRY(hipSetDevice(g->device));
+    int32_t rc = drain_events(g);
+    if (rc) return rc;
+    if (total_ms) *total_ms = g->kernel_ms;
+    if (launches) *launches = g->kernel_launches;
+    if (country_steps) *country_steps = g->kernel_country_steps;
     return EPI_OK;
 }
 
@@ -662,7 +725,8 @@ EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, doub
     for (int gs : g->greedy_steps) {
         if (gs > t0) {
             ea.t_begin = t0; ea.t_end = gs; ea.act_episode = nullptr;
-            HIP_TRY(launch_episode(ea, s));
+            rc = timed_episode(g, ea, s);
+            if (rc) return rc;
         }
         MlpArgs ma{};
         ma.rows = g_count * n; ma.n = n; ma.npad = npad;
@@ -672,12 +736,14 @@ EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, doub
         ma.act_episode = g->work.act_ep.as<int8_t>();
         HIP_TRY(launch_mlp(ma, s));
         ea.t_begin = gs; ea.t_end = gs + 1; ea.act_episode = ma.act_episode;
-        HIP_TRY(launch_episode(ea, s));
+        rc = timed_episode(g, ea, s);
+        if (rc) return rc;
         t0 = gs + 1;
     }
     if (t0 < g->steps) {
         ea.t_begin = t0; ea.t_end = g->steps; ea.act_episode = nullptr;
-        HIP_TRY(launch_episode(ea, s));
+        rc = timed_episode(g, ea, s);
+        if (rc) return rc;
     }
 
     LossArgs la{};

@@ -144,6 +144,12 @@ int32_t epi_grid_run(epi_grid *g, int32_t g_begin, int32_t g_count, double *loss
 /* Waits for the last enqueued run and returns its status (first failing grid point wins). */
 int32_t epi_grid_status(epi_grid *g);
 int32_t epi_grid_destroy(epi_grid *g);
+/* Measurement hooks (no counterpart in the reference).  With timing on, every launch of the episode
+ * kernel is bracketed by HIP events on its stream; epi_grid_kernel_time() returns the summed kernel
+ * time in ms, the number of launches and the country-steps those launches processed since timing
+ * was switched on. */
+int32_t epi_grid_set_timing(epi_grid *g, int32_t on);
+int32_t epi_grid_kernel_time(epi_grid *g, double *total_ms, int64_t *launches, int64_t *country_steps);
 /* First minimum in flat order with strict '<' starting from Double.MaxValue (Calibrate.scala:96,112). */
 int32_t epi_grid_argmin(const double *loss, int32_t count, int32_t *best_idx, double *best_loss);
 /* gridSurface in one call on one device: loss[n_beta*n_travel] beta-major; arrival/peak optional. */
