@@ -4,9 +4,11 @@
 // needs a HIP device and fails with EPI_ERR_DEVICE without one.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -129,6 +131,14 @@ int32_t normalise_row(const double* wrow_in, int n, int self, double* q_out, dou
     return EPI_OK;
 }
 
+// The kTopWeights largest entries of a normalised row, descending, zero padded.
+void top_weights(const double* q, int n, double* out) {
+    std::vector<double> v(q, q + n);
+    const int k = n < kTopWeights ? n : kTopWeights;
+    std::partial_sort(v.begin(), v.begin() + k, v.end(), [](double a, double b) { return a > b; });
+    for (int j = 0; j < kTopWeights; ++j) out[j] = j < k ? v[j] : 0.0;
+}
+
 // Dense row-major copy of the connection matrix from either input form.
 int32_t densify(int n, const double* conn, const int32_t* rowptr, const int32_t* col, const double* val,
                 std::vector<double>& W) {
@@ -154,7 +164,7 @@ int32_t densify(int n, const double* conn, const int32_t* rowptr, const int32_t*
 // Device-resident tables shared by the sweep and the world API.
 struct GraphTables {
     int n = 0, npad = 0;
-    DevBuf q, sumw, pop;
+    DevBuf q, sumw, pop, qtop;
     std::vector<double> W;  // dense host copy (seed-row variants are derived from it)
     int32_t build(int n_, const int32_t* pop_, const double* conn, const int32_t* rowptr, const int32_t* col,
                   const double* val) {
@@ -172,7 +182,10 @@ struct GraphTables {
             if (pop_[c] < 0) return fail(EPI_ERR_BAD_ARGUMENT, "pop[%d] = %d is negative", c, pop_[c]);
             hp[c] = pop_[c];
         }
+        std::vector<double> ht((size_t)n * kTopWeights, 0.0);
+        for (int i = 0; i < n; ++i) top_weights(&hq[(size_t)i * npad], n, &ht[(size_t)i * kTopWeights]);
         HIP_TRY(q.upload(hq));
+        HIP_TRY(qtop.upload(ht));
         HIP_TRY(sumw.upload(hs));
         HIP_TRY(pop.upload(hp));
         return EPI_OK;
@@ -277,7 +290,7 @@ struct epi_grid {
     int n = 0, npad = 0, steps = 0, n_beta = 0, n_travel = 0, seed_idx = 0;
     epi_state base{};
     GraphTables graph;
-    DevBuf qseed, sumw_seed, beta0, cst, actions, noise;
+    DevBuf qseed, sumw_seed, qtop_seed, beta0, cst, actions, noise;
     DevBuf t_arrive, has_arrive, t_peak, has_peak;
     MlpDevice mlp;
     std::vector<int> greedy_steps;
@@ -291,6 +304,7 @@ struct epi_grid {
     double kernel_ms = 0.0;
     long long kernel_launches = 0;
     long long kernel_country_steps = 0;
+    DevBuf stats;  // search statistics, allocated when EPI_STATS is set in the environment
 };
 
 struct epi_world {
@@ -508,7 +522,10 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
             rc = normalise_row(row.data(), n, d->seed_idx, &hq[(size_t)k * npad], &hs[k]);
             if (rc) return rc;
         }
+        std::vector<double> ht((size_t)(d->n_travel > 0 ? d->n_travel : 1) * kTopWeights, 0.0);
+        for (int k = 0; k < d->n_travel; ++k) top_weights(&hq[(size_t)k * npad], n, &ht[(size_t)k * kTopWeights]);
         HIP_TRY(G->qseed.upload(hq));
+        HIP_TRY(G->qtop_seed.upload(ht));
         HIP_TRY(G->sumw_seed.upload(hs));
     }
     // per-country environments (Calibrate.scala:31-51)
@@ -610,6 +627,18 @@ EPI_API int32_t epi_grid_destroy(epi_grid* g) {
     if (!g) return EPI_OK;
     (void)hipSetDevice(g->device);
     (void)drain_events(g);
+    if (g->stats.p) {
+        unsigned long long h[64];
+        if (hipMemcpy(h, g->stats.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int k = 0; k < 2; ++k) {
+                const unsigned long long* s = h + 32 * k;
+                fprintf(stderr, "[epi stats %s] rows %llu probes %llu (%.2f/row) cold %llu ties %llu hist:", k ? "I" : "S", s[0], s[1],
+                        s[0] ? (double)s[1] / (double)s[0] : 0.0, s[2], s[3]);
+                for (int b = 0; b < 28; ++b) fprintf(stderr, " %llu", s[4 + b]);
+                fprintf(stderr, "\n");
+            }
+        }
+    }
     delete g;
     return EPI_OK;
 }
@@ -715,11 +744,19 @@ EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, doub
     ea.validate = 1;
     ea.q = g->graph.q.as<double>(); ea.sumw = g->graph.sumw.as<double>();
     ea.qseed = g->qseed.as<double>(); ea.sumw_seed = g->sumw_seed.as<double>();
+    ea.qtop = g->graph.qtop.as<double>(); ea.qtop_seed = g->qtop_seed.as<double>();
     ea.beta0 = g->beta0.as<double>(); ea.beta_rows = g->n_beta > 0 ? g->n_beta : 1;
     ea.cst = g->cst.as<double>();
     ea.actions = g->actions.as<int8_t>(); ea.act_t0 = 0;
     ea.noise = g->noise.as<double>(); ea.noise_t0 = 0;
     ea.st = ia.st; ea.cap = ia.cap; ea.tcur = ia.tcur; ea.arrival = ia.arrival; ea.peak = ia.peak; ea.err = ia.err;
+    if (getenv("EPI_STATS")) {
+        if (!g->stats.p) {
+            HIP_TRY(g->stats.ensure(64 * sizeof(unsigned long long)));
+            HIP_TRY(hipMemset(g->stats.p, 0, 64 * sizeof(unsigned long long)));
+        }
+        ea.stats = g->stats.as<unsigned long long>();
+    }
 
     int t0 = 0;
     for (int gs : g->greedy_steps) {
@@ -982,6 +1019,7 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
     ea.validate = w->validate;
     ea.q = w->graph.q.as<double>(); ea.sumw = w->graph.sumw.as<double>();
     ea.qseed = nullptr; ea.sumw_seed = nullptr;
+    ea.qtop = w->graph.qtop.as<double>(); ea.qtop_seed = nullptr;
     ea.beta0 = w->beta0.as<double>(); ea.beta_rows = 1;
     ea.cst = w->cst.as<double>();
     ea.actions = nullptr; ea.act_episode = w->act_dev.as<int8_t>();

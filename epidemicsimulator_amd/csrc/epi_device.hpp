@@ -30,6 +30,7 @@ struct StepConsts {
     double vax7;    // MassVax: 0.05 * healthcareCapacity              :99
 };
 constexpr int kStepConstCount = 10;
+constexpr int kTopWeights = 128;  // sorted weights kept per row for the small-export shortcut
 
 __host__ __device__ inline StepConsts make_step_consts(const epi_env_params& e, const epi_profile& p) {
     StepConsts c;
@@ -265,28 +266,16 @@ __device__ __forceinline__ double frac_of(double raw) { return __builtin_amdgcn_
 
 __device__ __forceinline__ double from_hi_word(uint32_t hi) { return __hiloint2double((int)hi, 0); }
 
-__device__ __forceinline__ uint32_t next_threshold(uint32_t lo, uint32_t hi, int clo, int chi, int rem, int it) {
-    uint32_t mid;
-    const uint32_t span = hi - lo;
-    if (it % 3 == 2) {
-        mid = lo + (span >> 1);
-    } else {
-        // fraction of the way from lo (count clo) to hi (count chi) at which the count reaches rem
-        const float f = ((float)(clo - rem) + 0.5f) * __frcp_rn((float)(clo - chi));
-        if ((it & 1) == 0) {  // counts linear in the value
-            const double vlo = from_hi_word(lo), vhi = from_hi_word(hi);
-            const double t = vlo + (vhi - vlo) * (double)f;
-            mid = (uint32_t)__double2hiint(t);
-        } else {  // counts linear in the logarithm (the high word is exponent-major)
-            const uint32_t reach = 48u << 20;
-            const uint32_t lk = (span > reach) ? hi - reach : lo;
-            mid = lk + (uint32_t)((float)(hi - lk) * f);
-        }
-    }
-    mid = max(mid, lo + 1u);
-    mid = min(mid, hi - 1u);
-    return mid;
-}
+// Search memory of one (row, compartment): the threshold that solved the previous step, the
+// remainder it was solved for and the local density of fractions (count per unit value) there.
+// Exports change slowly from one day to the next, so the old solution plus a Newton step on the
+// new remainder lands within a few elements of the new threshold.  rho <= 0 marks "no memory".
+struct Warm {
+    uint32_t key;
+    float rho;
+    int32_t rem;
+    int32_t pad_;
+};
 
 // Exact finish for fractions whose high word equals K.  Members are the columns j < n with
 // hi32(frac_j) == K; `m` of them are selected by (low word descending, column ascending).
@@ -347,26 +336,41 @@ __device__ __noinline__ uint32_t tie_select(const double* __restrict__ qrow, dou
 }
 
 // Adds allocateInt(E, row)[j] into acc[r] for every column except `diag` (WorldToy.scala:121 drops
-// the origin's own entry).  E > 0.  All 64 lanes must be active.
+// the origin's own entry).  E > 0.  All 64 lanes must be active.  `warm` (LDS or global, may be
+// null) carries the search memory of this row and compartment between calls; it only steers the
+// order in which thresholds are tried, never the result.
+//
+// Threshold search.  Invariant: #{key >= lo} = clo > rem > chi = #{key >= hi}.  Every probe `mid`
+// lies strictly inside (lo, hi), so the bracket shrinks until a probe counts exactly rem (done:
+// the rem largest fractions are {key >= mid}) or hi == lo + 1 (fractions share a high word: exact
+// finish in tie_select).  Probe choice: Newton steps from the remembered solution / the last probe
+// with the remembered density, then interpolation inside the bracket (in the value, and on a cold
+// start alternately in the logarithm, since the high word is exponent-major), with a plain
+// bisection every fourth probe as the safeguard that bounds the iteration count.
 template <int R>
 __device__ __forceinline__ void apportion_row(int32_t E, int n, int diag, const double* __restrict__ qrow,
-                                              uint32_t (&acc)[R], int lane) {
+                                              uint32_t (&acc)[R], int lane, Warm* warm,
+                                              const double* __restrict__ qtop = nullptr,
+                                              unsigned long long* stats = nullptr) {
     const double Ed = (double)E;
     uint32_t key[R];
-    uint32_t bsum = 0, kmax = 0;
-    double q[R];
+    uint32_t bsum = 0;
+    {
+        double q[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) q[r] = qrow[r * 64 + lane];
+        for (int r = 0; r < R; ++r) q[r] = qrow[r * 64 + lane];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const double raw = q[r] * Ed;
-        const uint32_t b = (uint32_t)(int32_t)raw;  // raw >= 0: truncation is floor
-        key[r] = (uint32_t)__double2hiint(frac_of(raw));
-        acc[r] += b;
-        bsum += b;
-        kmax = max(kmax, key[r]);
+        for (int r = 0; r < R; ++r) {
+            const double raw = q[r] * Ed;
+            const uint32_t b = (uint32_t)(int32_t)raw;  // raw >= 0: truncation is floor
+            key[r] = (uint32_t)__double2hiint(frac_of(raw));
+            acc[r] += b;
+            bsum += b;
+        }
     }
-    const int32_t rem = (int32_t)((uint32_t)E - wave_sum(bsum));
+    const uint32_t base_total = wave_sum(bsum);
+    const int32_t rem = (int32_t)((uint32_t)E - base_total);
+    if (stats && lane == 0) atomicAdd(&stats[0], 1ull);
     if (rem <= 0) return;
     if (rem >= n) {  // every real column gets a unit (the reference stops at frac.length)
 #pragma unroll
@@ -376,30 +380,102 @@ __device__ __forceinline__ void apportion_row(int32_t E, int n, int diag, const 
         }
         return;
     }
-    uint32_t lo = 0, hi = wave_max(kmax) + 1u;
-    int clo = n, chi = 0, it = 0;
-    while (hi - lo > 1u) {
-        const uint32_t mid = next_threshold(lo, hi, clo, chi, rem, it);
-        uint32_t c = 0;
+    float rho = 0.f;
+    uint32_t pk = 0u;
+    int32_t prem = 0;
+    if (warm) {
+        rho = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(warm->rho)));
+        pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)warm->key);
+        prem = __builtin_amdgcn_readfirstlane(warm->rem);
+    }
+    const bool cold = !(rho > 0.f);
+    uint32_t lo = 0u, hi = 0x3ff00000u;  // every fraction is below 1.0
+    if (cold) {
+        uint32_t kmax = 0u;
 #pragma unroll
-        for (int r = 0; r < R; ++r) c += (key[r] >= mid);
-        c = wave_sum(c);
-        if ((int)c == rem) {
+        for (int r = 0; r < R; ++r) kmax = max(kmax, key[r]);
+        hi = wave_max(kmax) + 1u;
+    }
+    int clo = n, chi = 0, it = 0, last_c = -1;
+    uint32_t last_k = 0u;
+    bool lo_probed = false, hi_probed = false;
+    // No column received a whole unit: every fraction is the product q_j * E itself, so the rem = E
+    // largest are the E largest weights of the row.  qtop holds the row's kTopWeights largest
+    // weights in descending order; the E-th of them times E is the threshold to try first.
+    uint32_t hint = 0u;
+    if (qtop && base_total == 0u && E < kTopWeights)
+        hint = (uint32_t)__double2hiint(qtop[E - 1] * Ed);
+    while (hi - lo > 1u) {
+        uint32_t mid;
+        if (it == 0 && hint != 0u) {
+            mid = hint;
+        } else if (!cold && it < 4 && !(lo_probed && hi_probed)) {
+            const uint32_t bk = it == 0 ? pk : last_k;
+            const int bc = it == 0 ? prem : last_c;
+            const double t = from_hi_word(bk) + (double)((float)(bc - rem) / rho);
+            mid = t > 0.0 ? (uint32_t)__double2hiint(t) : 0u;
+        } else if ((it & 3) == 3) {
+            mid = lo + ((hi - lo) >> 1);
+        } else {
+            // fraction of the way from lo to hi at which the count is expected to reach rem
+            const float f = ((float)(clo - rem) + 0.5f) / (float)(clo - chi + 1);
+            if (it & 1) {
+                const uint32_t reach = 64u << 20;
+                const uint32_t lk = (hi - lo > reach) ? hi - reach : lo;
+                mid = lk + (uint32_t)((float)(hi - lk) * f);
+            } else {
+                const double vlo = from_hi_word(lo), vhi = from_hi_word(hi);
+                mid = (uint32_t)__double2hiint(vlo + (vhi - vlo) * (double)f);
+            }
+        }
+        mid = max(mid, lo + 1u);
+        mid = min(mid, hi - 1u);
+        uint32_t cu = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) cu += (key[r] >= mid);
+        const int c = (int)wave_sum(cu);
+        if (last_c >= 0 && abs(c - last_c) >= 3 && mid != last_k) {
+            const float r2 = (float)(last_c - c) / (float)(from_hi_word(mid) - from_hi_word(last_k));
+            if (r2 > 0.f) rho = r2;
+        }
+        last_k = mid;
+        last_c = c;
+        if (c == rem) {
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r] += (key[r] >= mid);
+            if (stats && lane == 0) {
+                atomicAdd(&stats[1], (unsigned long long)(it + 1));
+                atomicAdd(&stats[2], cold ? 1ull : 0ull);
+                atomicAdd(&stats[4 + min(it, 27)], 1ull);
+            }
+            if (warm && lane == 0) {
+                if (!(rho > 0.f)) rho = (float)(clo - chi) / (float)(from_hi_word(hi) - from_hi_word(lo));
+                warm->key = mid;
+                warm->rho = rho;
+                warm->rem = rem;
+            }
             return;
         }
-        if ((int)c > rem) { lo = mid; clo = (int)c; }
-        else { hi = mid; chi = (int)c; }
+        if (c > rem) { lo = mid; clo = c; lo_probed = true; }
+        else { hi = mid; chi = c; hi_probed = true; }
         ++it;
     }
     // two or more fractions share the pivot's high word `lo`
+    if (stats && lane == 0) {
+        atomicAdd(&stats[1], (unsigned long long)it);
+        atomicAdd(&stats[3], 1ull);
+    }
     const uint32_t sel = tie_select<R>(qrow, Ed, lo, rem - chi, n, lane);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int j = r * 64 + lane;
         const bool take = (key[r] > lo) || ((sel >> r) & 1u);
         acc[r] += (take && j != diag);
+    }
+    if (warm && lane == 0 && rho > 0.f) {
+        warm->key = lo;
+        warm->rho = rho;
+        warm->rem = rem;
     }
 }
 

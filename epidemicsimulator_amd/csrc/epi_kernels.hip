@@ -41,6 +41,7 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
     __shared__ unsigned long long sh_mass[2][2];
     __shared__ int sh_next_row;
     __shared__ int sh_err[4];
+    __shared__ Warm sh_warm[2][NP];  // threshold-search memory per (compartment, row)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -64,6 +65,8 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
     int32_t arrival = a.arrival[eoff + tid];
     int32_t peak = a.peak[eoff + tid];
     int32_t last_flow_s = 0, last_flow_i = 0;
+    sh_warm[0][tid].rho = 0.f;
+    sh_warm[1][tid].rho = 0.f;
     if (tid == 0) {
         sh_mass[0][0] = sh_mass[0][1] = sh_mass[1][0] = sh_mass[1][1] = 0ull;
         sh_err[0] = sh_err[1] = sh_err[2] = sh_err[3] = 0;
@@ -138,8 +141,13 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
                 if ((ES | EI) == 0) continue;
                 const double* __restrict__ qrow =
                     (row == a.seed_idx && a.qseed) ? a.qseed + (size_t)ti * NP : a.q + (size_t)row * NP;
-                if (ES > 0) apportion_row<R>(ES, n, row, qrow, accS, lane);
-                if (EI > 0) apportion_row<R>(EI, n, row, qrow, accI, lane);
+                const double* __restrict__ qtop =
+                    !a.qtop ? nullptr
+                            : ((row == a.seed_idx && a.qseed) ? a.qtop_seed + (size_t)ti * kTopWeights
+                                                              : a.qtop + (size_t)row * kTopWeights);
+                if (ES > 0) apportion_row<R>(ES, n, row, qrow, accS, lane, &sh_warm[0][row], qtop, a.stats);
+                if (EI > 0)
+                    apportion_row<R>(EI, n, row, qrow, accI, lane, &sh_warm[1][row], qtop, a.stats ? a.stats + 32 : nullptr);
                 any = true;
             }
             if (any) {
@@ -434,7 +442,7 @@ __global__ __launch_bounds__(64) void alloc_batch_kernel(const AllocBatchArgs a)
 #pragma unroll
         for (int r = 0; r < R; ++r) sh_q[r * 64 + lane] = sh_q[r * 64 + lane] / sum;
         __syncthreads();
-        apportion_row<R>(total, n, -1, sh_q, acc, lane);
+        apportion_row<R>(total, n, -1, sh_q, acc, lane, nullptr);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {

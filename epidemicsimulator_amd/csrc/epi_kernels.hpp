@@ -27,6 +27,8 @@ struct EpisodeArgs {
     const double* sumw;      // [npad]     max(0, sum_j wRow_j)  (WorldToy.scala:114)
     const double* qseed;     // [n_travel][npad] seed-row variants (ToyConn.scaleRow per travel scale)
     const double* sumw_seed; // [n_travel]
+    const double* qtop;      // [n][kTopWeights] each row's largest normalised weights, descending (or NULL)
+    const double* qtop_seed; // [n_travel][kTopWeights]
     const double* beta0;     // [n_beta][npad] or [1][npad]
     int beta_rows;           // rows in beta0; episode uses row min(g / n_travel, beta_rows-1)
     const double* cst;       // [CST_COUNT][npad]
@@ -47,6 +49,7 @@ struct EpisodeArgs {
     double* reward_out;      // [count][npad]
     int32_t* flow_s;         // [count][npad] movedS of the last step (WorldToy.scala:106-126)
     int32_t* flow_i;
+    unsigned long long* stats;  // optional [32] search statistics: rows, probes, cold starts, ties, histogram
 };
 
 struct InitArgs {
