@@ -111,23 +111,16 @@ def main():
                        wl["profiles"], wl["betas"], wl["travel"], wl["t_arrive"], wl["t_peak"], True, device=local_rank)
 
     # contiguous beta-major slabs, padded so that the all-gather pieces have equal size
-    per = (G + world - 1) // world
-    g0 = min(G, rank * per)
-    cnt = max(0, min(G, g0 + per) - g0)
+    from epidemicsimulator_amd.dist import gather_surface, slab_bounds
+    g0, cnt, per = slab_bounds(G, world, rank)
     loss_local = torch.zeros(per, dtype=torch.float64, device="cuda")
-    loss_all = torch.zeros(per * world, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def one_step():
         if cnt > 0:
             eng.enqueue(g0, cnt, loss_local.data_ptr(), stream)
-        if world > 1:
-            dist.all_gather_into_tensor(loss_all, loss_local)
-            surface = loss_all
-        else:
-            surface = loss_local
-        host = surface.cpu().numpy()  # 8*G bytes; the argmin is Calibrate.scala:112's strict '<' scan
-        return E.grid_argmin(host[:G])
+        host = gather_surface(loss_local, G, world)  # 8*G bytes back to the host
+        return E.grid_argmin(host)                   # Calibrate.scala:112's strict '<' scan
 
     def fence():
         if world > 1:

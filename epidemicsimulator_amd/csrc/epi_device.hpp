@@ -267,9 +267,10 @@ __device__ __forceinline__ double frac_of(double raw) { return __builtin_amdgcn_
 __device__ __forceinline__ double from_hi_word(uint32_t hi) { return __hiloint2double((int)hi, 0); }
 
 // Search memory of one (row, compartment): the threshold that solved the previous step, the
-// remainder it was solved for and the local density of fractions (count per unit value) there.
-// Exports change slowly from one day to the next, so the old solution plus a Newton step on the
-// new remainder lands within a few elements of the new threshold.  rho <= 0 marks "no memory".
+// remainder it was solved for and the reciprocal density of fractions there (`rho`: value units per
+// element).  Exports change slowly from one day to the next, so the old solution plus a Newton
+// step on the new remainder lands within a few elements of the new threshold.  rho <= 0 marks
+// "no memory".
 struct Warm {
     uint32_t key;
     float rho;
@@ -380,15 +381,17 @@ __device__ __forceinline__ void apportion_row(int32_t E, int n, int diag, const 
         }
         return;
     }
-    float rho = 0.f;
+    // Wave-uniform search state lives in scalar registers: every value that steers the loop is
+    // passed through readfirstlane so that the branches below are scalar branches.
+    float slope = 0.f;  // value units per element near the threshold (reciprocal density); <= 0: none
     uint32_t pk = 0u;
     int32_t prem = 0;
     if (warm) {
-        rho = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(warm->rho)));
+        slope = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(warm->rho)));
         pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)warm->key);
         prem = __builtin_amdgcn_readfirstlane(warm->rem);
     }
-    const bool cold = !(rho > 0.f);
+    const bool cold = !(slope > 0.f);
     uint32_t lo = 0u, hi = 0x3ff00000u;  // every fraction is below 1.0
     if (cold) {
         uint32_t kmax = 0u;
@@ -404,21 +407,22 @@ __device__ __forceinline__ void apportion_row(int32_t E, int n, int diag, const 
     // weights in descending order; the E-th of them times E is the threshold to try first.
     uint32_t hint = 0u;
     if (qtop && base_total == 0u && E < kTopWeights)
-        hint = (uint32_t)__double2hiint(qtop[E - 1] * Ed);
+        hint = (uint32_t)__builtin_amdgcn_readfirstlane(__double2hiint(qtop[E - 1] * Ed));
+    bool found = false;
+    uint32_t mid = 0u;
     while (hi - lo > 1u) {
-        uint32_t mid;
         if (it == 0 && hint != 0u) {
             mid = hint;
         } else if (!cold && it < 4 && !(lo_probed && hi_probed)) {
             const uint32_t bk = it == 0 ? pk : last_k;
             const int bc = it == 0 ? prem : last_c;
-            const double t = from_hi_word(bk) + (double)((float)(bc - rem) / rho);
+            const double t = from_hi_word(bk) + (double)((float)(bc - rem) * slope);
             mid = t > 0.0 ? (uint32_t)__double2hiint(t) : 0u;
         } else if ((it & 3) == 3) {
             mid = lo + ((hi - lo) >> 1);
         } else {
             // fraction of the way from lo to hi at which the count is expected to reach rem
-            const float f = ((float)(clo - rem) + 0.5f) / (float)(clo - chi + 1);
+            const float f = ((float)(clo - rem) + 0.5f) * __builtin_amdgcn_rcpf((float)(clo - chi + 1));
             if (it & 1) {
                 const uint32_t reach = 64u << 20;
                 const uint32_t lk = (hi - lo > reach) ? hi - reach : lo;
@@ -430,51 +434,46 @@ __device__ __forceinline__ void apportion_row(int32_t E, int n, int diag, const 
         }
         mid = max(mid, lo + 1u);
         mid = min(mid, hi - 1u);
+        mid = (uint32_t)__builtin_amdgcn_readfirstlane((int)mid);
         uint32_t cu = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) cu += (key[r] >= mid);
         const int c = (int)wave_sum(cu);
         if (last_c >= 0 && abs(c - last_c) >= 3 && mid != last_k) {
-            const float r2 = (float)(last_c - c) / (float)(from_hi_word(mid) - from_hi_word(last_k));
-            if (r2 > 0.f) rho = r2;
+            const float s2 = (float)(from_hi_word(mid) - from_hi_word(last_k)) * __builtin_amdgcn_rcpf((float)(last_c - c));
+            if (s2 > 0.f) slope = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s2)));
         }
         last_k = mid;
         last_c = c;
-        if (c == rem) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] += (key[r] >= mid);
-            if (stats && lane == 0) {
-                atomicAdd(&stats[1], (unsigned long long)(it + 1));
-                atomicAdd(&stats[2], cold ? 1ull : 0ull);
-                atomicAdd(&stats[4 + min(it, 27)], 1ull);
-            }
-            if (warm && lane == 0) {
-                if (!(rho > 0.f)) rho = (float)(clo - chi) / (float)(from_hi_word(hi) - from_hi_word(lo));
-                warm->key = mid;
-                warm->rho = rho;
-                warm->rem = rem;
-            }
-            return;
-        }
+        ++it;
+        if (c == rem) { found = true; break; }
         if (c > rem) { lo = mid; clo = c; lo_probed = true; }
         else { hi = mid; chi = c; hi_probed = true; }
-        ++it;
     }
-    // two or more fractions share the pivot's high word `lo`
     if (stats && lane == 0) {
         atomicAdd(&stats[1], (unsigned long long)it);
-        atomicAdd(&stats[3], 1ull);
+        atomicAdd(&stats[2], cold ? 1ull : 0ull);
+        if (found) atomicAdd(&stats[4 + min(it - 1, 27)], 1ull);
+        else atomicAdd(&stats[3], 1ull);
     }
-    const uint32_t sel = tie_select<R>(qrow, Ed, lo, rem - chi, n, lane);
+    if (found) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int j = r * 64 + lane;
-        const bool take = (key[r] > lo) || ((sel >> r) & 1u);
-        acc[r] += (take && j != diag);
+        for (int r = 0; r < R; ++r) acc[r] += (key[r] >= mid);
+        if (!(slope > 0.f)) slope = (float)(from_hi_word(hi) - from_hi_word(lo)) * __builtin_amdgcn_rcpf((float)(clo - chi));
+    } else {
+        // two or more fractions share the pivot's high word `lo`
+        const uint32_t sel = tie_select<R>(qrow, Ed, lo, rem - chi, n, lane);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j = r * 64 + lane;
+            const bool take = (key[r] > lo) || ((sel >> r) & 1u);
+            acc[r] += (take && j != diag);
+        }
+        mid = lo;
     }
-    if (warm && lane == 0 && rho > 0.f) {
-        warm->key = lo;
-        warm->rho = rho;
+    if (warm && lane == 0 && slope > 0.f) {
+        warm->key = mid;
+        warm->rho = slope;
         warm->rem = rem;
     }
 }

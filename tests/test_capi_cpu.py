@@ -1,0 +1,145 @@
+"""CPU tests of the C ABI: the library loads, exports every symbol include/epi.h declares, its host-side
+JVM-compatible streams match the oracle, and every compute entry point refuses to run without a GPU
+(there is no CPU fallback behind the ABI)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def epi():
+    import epidemicsimulator_amd as E
+    E.lib()
+    return E
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "epi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(epi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(epi):
+    from epidemicsimulator_amd import _capi
+    names = header_functions()
+    assert len(names) >= 25
+    L = epi.lib()
+    for name in names:
+        assert hasattr(L, name), "libepi.so does not export %s" % name
+    assert sorted(_capi.EXPORTED_SYMBOLS) == names
+    assert L.epi_version() >= 100
+
+
+def test_struct_layouts_match_header(epi):
+    from epidemicsimulator_amd import _capi
+    assert C.sizeof(_capi.CState) == 64 and C.sizeof(_capi.Profile) == 72 and C.sizeof(_capi.EnvParams) == 48
+    assert C.sizeof(_capi.CHyper) == 48
+    assert C.sizeof(O.State) == C.sizeof(_capi.CState)
+
+
+def test_host_streams_match_oracle(epi, oracle):
+    L = epi.lib()
+    for seed in (0, 7, 9, 42, 1041):
+        out = np.zeros(300)
+        assert L.epi_java_gaussians(C.c_int64(seed), 300, out.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        np.testing.assert_array_equal(out, O.jrand_gaussians(seed, 300))
+    hp = epi.HyperParams()._c()
+    acts = np.zeros(600, dtype=np.int32)
+    assert L.epi_agent_actions(C.byref(hp), 600, acts.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+    assert acts[:10].tolist() == [6, 6, 7, 2, 4, 0, 2, 3, 2, 6]
+    assert np.flatnonzero(acts < 0)[:2].tolist() == [113, 455]
+    W = epi.mlp_init(128)
+    for a, b in zip(W, O.mlp_weights()):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_scale_row_matches_oracle(epi, oracle):
+    rng = np.random.default_rng(2)
+    for n in (2, 6, 33):
+        W = rng.random((n, n)) * 0.05
+        np.fill_diagonal(W, 0.0)
+        for row in (0, n - 1):
+            for f in (0.0, 0.5, 1.0, 3.0, 40.0):
+                np.testing.assert_array_equal(epi.ToyConn.scale_row(W, row, f), O.scale_row(W, row, f))
+    A = epi.ToyConn.scale_row(epi.ToyConn.W, 0, 9.0)
+    assert A[0, 0] == 0.0 and abs(A[0].sum() - 0.2) < 1e-12
+    np.testing.assert_array_equal(A[1:], epi.ToyConn.W[1:])
+
+
+def test_argmin_is_first_minimum(epi):
+    from epidemicsimulator_amd.dist import first_min
+    assert epi.grid_argmin([3.0, 1.0, 1.0, 2.0]) == (1, 1.0)
+    assert epi.grid_argmin([]) == (0, 1.7976931348623157e308)
+    assert epi.grid_argmin([float("inf"), float("nan")]) == (0, 1.7976931348623157e308)
+    rng = np.random.default_rng(0)
+    x = np.round(rng.random(500), 2)
+    assert epi.grid_argmin(x) == first_min(x) == (int(np.argmin(x)), float(x.min()))
+
+
+def test_validation_mirror(epi):
+    V = epi.Validation
+    V.assert_state(epi.State(9, 1, 0, 0, 0, 10, 0, 10, 1), V.Invariants(10, 10))
+    with pytest.raises(epi.IllegalArgumentException):
+        V.assert_state(epi.State(9, 2, 0, 0, 0, 10, 0, 10, 1), V.Invariants(10, 10))
+    with pytest.raises(epi.IllegalArgumentException):
+        V.assert_state(epi.State(9, 1, 0, 0, 0, 10, 11, 10, 1), V.Invariants(10, 10))
+    assert V.arrival_time([1.0, 2.0, 3.0, 4.0, 5.0], 10.0) == 5
+    assert V.peak_i([]) == 0.0 and abs(V.peak_i([0.1, 0.5, 0.3]) - 0.5) <= 1e-12
+    assert epi.Action.from_id(-3) == epi.Action.NoneA and epi.Action.from_id(99) == epi.Action.MassVax
+
+
+def test_toy_matrix_properties(epi):
+    W = epi.ToyConn.W
+    assert W.shape == (6, 6)
+    for i in range(6):
+        assert W[i, i] == 0.0 and W[i].sum() <= 0.12 + 1e-12
+    assert epi.ToyConn.W2[5, 3] == W[5, 3] * 3.0
+
+
+def test_compute_entry_points_need_a_gpu(epi):
+    if epi.lib().epi_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(epi.EpiError) as ei:
+        epi.EpidemicEnv.allocate_int(10, [1, 1, 1])
+    assert ei.value.status == 2
+    from epidemicsimulator_amd import synth
+    wl = synth.small_workload(8, 1, 1, 3)
+    with pytest.raises(epi.EpiError) as ei:
+        epi.GridEngine(epi.HyperParams(), 3, synth.base_state(3), 0, [c.pop for c in wl["countries"]], wl["conn"],
+                       wl["profiles"], wl["betas"], wl["travel"])
+    assert "HIP" in str(ei.value)
+    with pytest.raises(epi.EpiError):
+        epi.WorldToy(epi.HyperParams(), synth.base_state(3))
+
+
+def test_bad_arguments_are_rejected_before_the_device(epi):
+    from epidemicsimulator_amd import synth
+    wl = synth.small_workload(8, 1, 1, 3)
+    with pytest.raises(epi.IllegalArgumentException):      # Validation.assertState on the initial states
+        epi.GridEngine(epi.HyperParams(), 3, synth.base_state(3).copy(r=2.0), 0, [c.pop for c in wl["countries"]], wl["conn"],
+                       wl["profiles"], wl["betas"], wl["travel"])
+    with pytest.raises(epi.EpiError):
+        epi.GridEngine(epi.HyperParams(), 3, synth.base_state(3), 99, [c.pop for c in wl["countries"]], wl["conn"],
+                       wl["profiles"], wl["betas"], wl["travel"])
+
+
+def test_synthetic_inputs_are_deterministic(epi):
+    from epidemicsimulator_amd import synth
+    a = synth.workload("c2"); b = synth.workload("c2")
+    np.testing.assert_array_equal(a["conn"], b["conn"])
+    assert [c.pop for c in a["countries"]] == [c.pop for c in b["countries"]]
+    W = a["conn"]
+    assert W.shape == (200, 200) and (np.diag(W) == 0).all() and (W.sum(1) <= 0.12 + 1e-12).all() and (W >= 0).all()
+    assert synth.splitmix64(0, 1)[0] == np.uint64(0xE220A8397B1DCDAF)
+    rp, col, val = synth.gravity_csr(*synth.make_countries(300, 3), 3, 5.0)
+    assert rp[-1] == len(col) and (np.diff(rp) >= 1).all()
+    for i in range(300):
+        c = col[rp[i]:rp[i + 1]]
+        assert (np.diff(c) > 0).all() and i not in c

@@ -1,0 +1,85 @@
+"""The multi-GPU path on CPU: two ranks over gloo run the same slab partition, all-gather and
+first-minimum scan that bench.py runs over RCCL.  The per-point losses come from the oracle here (the
+engine needs a GPU); what is under test is the exchange: slab bounds, padding, gather order, argmin."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, grid_points, surface, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from epidemicsimulator_amd.dist import first_min, gather_surface, slab_bounds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g0, cnt, per = slab_bounds(grid_points, world, rank)
+    local = torch.zeros(per, dtype=torch.float64)
+    local[:cnt] = torch.from_numpy(surface[g0:g0 + cnt])  # this rank's slab of the loss surface
+    full = gather_surface(local, grid_points, world)
+    idx, best = first_min(full)
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.concatenate([full, [idx, best]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grid_points", [12, 7, 1])
+def test_two_rank_gather_and_argmin(tmp_path, grid_points):
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(grid_points)
+    surface = np.round(rng.random(grid_points) * 10, 1)  # coarse values: repeated minima exercise "first"
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, grid_points, surface, str(tmp_path)), nprocs=2, join=True)
+    want_idx = int(np.argmin(surface))
+    for rank in range(2):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % rank))
+        np.testing.assert_array_equal(got[:grid_points], surface)
+        assert int(got[grid_points]) == want_idx and got[grid_points + 1] == surface[want_idx]
+
+
+def test_slab_bounds_cover_the_grid():
+    sys.path.insert(0, ROOT)
+    from epidemicsimulator_amd.dist import slab_bounds
+    for G in (0, 1, 7, 20, 1024, 4096, 4097):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            pers = set()
+            for r in range(world):
+                g0, cnt, per = slab_bounds(G, world, r)
+                seen += list(range(g0, g0 + cnt))
+                pers.add(per)
+                assert cnt <= per
+            assert seen == list(range(G)) and len(pers) == 1
+    assert slab_bounds(4096, 8, 3) == (1536, 512, 512)
+
+
+def test_oracle_surface_through_the_exchange(tmp_path, oracle):
+    """The toy 2x3 surface computed by the oracle, cut into two slabs, gathered over gloo."""
+    import torch.multiprocessing as mp
+    from epidemicsimulator_amd import Geo, ToyConn
+    from oracle import oracle_lib as O
+    from tests import util
+    names = [c.name for c in ToyConn.C]
+    profs = [util.prof_dict(Geo.CountryProfiles.get_profile(n)) for n in names]
+    ones = np.ones(6, dtype=np.uint8)
+    out = O.grid_surface([c.pop for c in ToyConn.C], ToyConn.W, 0, O.State(1e6, 0, 0, 0, 0, 10000.0, 0, 40, 1, 0), profs, 40,
+                         [0.24, 0.27], [0.5, 0.7, 0.9], np.full(6, 50.0), ones, np.full(6, 1e4), ones, True)
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, 6, out["loss"], str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "rank1.npy"))
+    np.testing.assert_array_equal(got[:6], out["loss"])
+    assert int(got[6]) == out["best_idx"] and got[7] == out["best_loss"]
