@@ -12,10 +12,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libepi.so")
 
 EPI_OK, EPI_ERR_BAD_ARGUMENT, EPI_ERR_DEVICE, EPI_ERR_LOCAL_MASS, EPI_ERR_WORLD_MASS, EPI_ERR_ASSERT_STATE, \
-    EPI_ERR_INT_RANGE = range(7)
+    EPI_ERR_INT_RANGE, EPI_ERR_UNSUPPORTED = range(8)
 
 STATUS_NAMES = {0: "EPI_OK", 1: "EPI_ERR_BAD_ARGUMENT", 2: "EPI_ERR_DEVICE", 3: "EPI_ERR_LOCAL_MASS",
-                4: "EPI_ERR_WORLD_MASS", 5: "EPI_ERR_ASSERT_STATE", 6: "EPI_ERR_INT_RANGE"}
+                4: "EPI_ERR_WORLD_MASS", 5: "EPI_ERR_ASSERT_STATE", 6: "EPI_ERR_INT_RANGE", 7: "EPI_ERR_UNSUPPORTED"}
 
 
 class EpiError(RuntimeError):

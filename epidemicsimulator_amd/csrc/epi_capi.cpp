@@ -166,9 +166,102 @@ struct GraphTables {
     int n = 0, npad = 0;
     DevBuf q, sumw, pop, qtop;
     std::vector<double> W;  // dense host copy (seed-row variants are derived from it)
+    // sparse mode (n > kMaxDenseN): CSR arrays on the device, raw weights on the host
+    bool sparse = false;
+    int max_deg = 0;
+    DevBuf d_rowptr, d_col, d_qval;
+    std::vector<int32_t> h_rowptr, h_col;
+    std::vector<double> h_val;
+
+    // Normalises one stored row in column order: the reference sums the full row left to right, and
+    // adding the zeros of the entries that are not stored changes no partial sum.
+    static int32_t normalise_sparse_row(const double* val, const int32_t* col, int deg, int self, double* q_out,
+                                        double* sumw_out) {
+        double sum = 0.0;
+        for (int k = 0; k < deg; ++k) {
+            const double w = (col[k] == self) ? 0.0 : val[k];
+            if (!std::isfinite(w) || w < 0.0)
+                return fail(EPI_ERR_BAD_ARGUMENT, "connection weight (%d,%d) = %g: weights must be finite and >= 0", self, col[k], w);
+            sum = (k == 0) ? w : sum + w;
+        }
+        *sumw_out = std::fmax(0.0, sum);
+        for (int k = 0; k < deg; ++k) {
+            const double w = (col[k] == self) ? 0.0 : val[k];
+            q_out[k] = (sum > 0.0) ? w / sum : 0.0;
+        }
+        return EPI_OK;
+    }
+
+    int32_t build_sparse(const int32_t* pop_, const double* conn, const int32_t* rowptr, const int32_t* col,
+                         const double* val) {
+        sparse = true;
+        npad = (n + 63) / 64 * 64;
+        if (csr_lds_bytes(n) > kMaxLdsBytes)
+            return fail(EPI_ERR_UNSUPPORTED, "n = %d patches: the sparse kernel keeps 8 bytes of inflow per patch in the %zu KiB of LDS", n, kMaxLdsBytes / 1024);
+        h_rowptr.assign((size_t)n + 1, 0);
+        h_col.clear();
+        h_val.clear();
+        if (rowptr && col && val) {
+            for (int i = 0; i < n; ++i) {
+                int prev = -1;
+                for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+                    if (col[k] < 0 || col[k] >= n || col[k] <= prev)
+                        return fail(EPI_ERR_BAD_ARGUMENT, "CSR row %d: column indices must be ascending and in [0,n)", i);
+                    prev = col[k];
+                    h_col.push_back(col[k]);
+                    h_val.push_back(val[k]);
+                }
+                h_rowptr[i + 1] = (int32_t)h_col.size();
+            }
+        } else if (conn) {
+            for (int i = 0; i < n; ++i) {
+                for (int j = 0; j < n; ++j)
+                    if (conn[(size_t)i * n + j] != 0.0 && j != i) { h_col.push_back(j); h_val.push_back(conn[(size_t)i * n + j]); }
+                h_rowptr[i + 1] = (int32_t)h_col.size();
+            }
+        } else {
+            return fail(EPI_ERR_BAD_ARGUMENT, "neither a dense matrix nor a CSR triple was given");
+        }
+        max_deg = 0;
+        for (int i = 0; i < n; ++i) max_deg = std::max(max_deg, h_rowptr[i + 1] - h_rowptr[i]);
+        if (max_deg > kMaxSparseDegree)
+            return fail(EPI_ERR_UNSUPPORTED, "a row stores %d weights: worlds of more than %d patches support at most %d per row", max_deg, kMaxDenseN, kMaxSparseDegree);
+        std::vector<double> hq(h_val.size() ? h_val.size() : 1, 0.0), hs((size_t)npad, 0.0);
+        for (int i = 0; i < n; ++i) {
+            const int rs = h_rowptr[i], deg = h_rowptr[i + 1] - rs;
+            int32_t rc = normalise_sparse_row(h_val.data() + rs, h_col.data() + rs, deg, i, hq.data() + rs, &hs[i]);
+            if (rc) return rc;
+        }
+        std::vector<int32_t> hp((size_t)npad, 0);
+        for (int c = 0; c < n; ++c) {
+            if (pop_[c] < 0) return fail(EPI_ERR_BAD_ARGUMENT, "pop[%d] = %d is negative", c, pop_[c]);
+            hp[c] = pop_[c];
+        }
+        if (h_col.empty()) h_col.push_back(0);
+        HIP_TRY(d_rowptr.upload(h_rowptr));
+        HIP_TRY(d_col.upload(h_col));
+        HIP_TRY(d_qval.upload(hq));
+        HIP_TRY(sumw.upload(hs));
+        HIP_TRY(pop.upload(hp));
+        return EPI_OK;
+    }
+
+    void fill(EpisodeArgs& ea) const {
+        ea.sumw = sumw.as<double>();
+        if (sparse) {
+            ea.q = nullptr; ea.qtop = nullptr;
+            ea.rowptr = d_rowptr.as<int32_t>(); ea.col = d_col.as<int32_t>(); ea.qval = d_qval.as<double>();
+            ea.max_deg = max_deg;
+        } else {
+            ea.q = q.as<double>(); ea.qtop = qtop.as<double>();
+            ea.rowptr = nullptr;
+        }
+    }
+
     int32_t build(int n_, const int32_t* pop_, const double* conn, const int32_t* rowptr, const int32_t* col,
                   const double* val) {
         n = n_;
+        if (n > kMaxDenseN) return build_sparse(pop_, conn, rowptr, col, val);
         npad = dense_slots_for(n) * 64;
         int32_t rc = densify(n, conn, rowptr, col, val, W);
         if (rc) return rc;
@@ -195,9 +288,9 @@ struct GraphTables {
 // Per-episode work buffers.
 struct EpisodeBuffers {
     int count = 0, npad = 0;
-    DevBuf st, cap, tcur, arrival, peak, err, act_ep;
-    int32_t ensure(int count_, int npad_) {
-        if (count_ <= count && npad_ == npad) return EPI_OK;
+    DevBuf st, cap, tcur, arrival, peak, err, act_ep, exports;
+    int32_t ensure(int count_, int npad_, bool sparse = false) {
+        if (count_ <= count && npad_ == npad && (!sparse || exports.p)) return EPI_OK;
         const size_t cells = (size_t)count_ * npad_;
         HIP_TRY(st.ensure(cells * 5 * sizeof(int32_t)));
         HIP_TRY(cap.ensure(cells * sizeof(double)));
@@ -206,6 +299,7 @@ struct EpisodeBuffers {
         HIP_TRY(peak.ensure(cells * sizeof(int32_t)));
         HIP_TRY(err.ensure((size_t)count_ * 4 * sizeof(int32_t)));
         HIP_TRY(act_ep.ensure(cells));
+        if (sparse) HIP_TRY(exports.ensure(cells * 2 * sizeof(int32_t)));
         count = count_;
         npad = npad_;
         return EPI_OK;
@@ -248,6 +342,7 @@ const char* status_text(int code) {
         case EPI_ERR_LOCAL_MASS: return "requirement failed: mass not conserved (local)";
         case EPI_ERR_WORLD_MASS: return "requirement failed: global mass changed during mobility";
         case EPI_ERR_INT_RANGE: return "a compartment left the 32-bit Int range the reference computes in";
+        case EPI_ERR_UNSUPPORTED: return "more units left over than positive fractions in a sparse row";
         default: return "device-side failure";
     }
 }
@@ -287,7 +382,7 @@ int32_t assert_initial(const epi_state& b) {
 // ================================================================================================
 struct epi_grid {
     int device = 0;
-    int n = 0, npad = 0, steps = 0, n_beta = 0, n_travel = 0, seed_idx = 0;
+    int n = 0, npad = 0, steps = 0, n_beta = 0, n_travel = 0, seed_idx = 0, seed_deg = 0;
     epi_state base{};
     GraphTables graph;
     DevBuf qseed, sumw_seed, qtop_seed, beta0, cst, actions, noise;
@@ -491,8 +586,6 @@ EPI_API int32_t epi_mlp_greedy_batch(const epi_state* states, int32_t batch, int
 // ================================================================================================
 static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
     if (d->n < 1) return fail(EPI_ERR_BAD_ARGUMENT, "grid: n = %d", d->n);
-    if (d->n > kMaxDenseN)
-        return fail(EPI_ERR_BAD_ARGUMENT, "grid: n = %d countries exceeds the %d the register-resident row kernel holds", d->n, kMaxDenseN);
     if (!d->pop || d->seed_idx < 0 || d->seed_idx >= d->n || d->steps < 0 || d->n_beta < 0 || d->n_travel < 0)
         return fail(EPI_ERR_BAD_ARGUMENT, "grid: bad sizes or null pop");
     if ((d->n_beta > 0 && !d->betas) || (d->n_travel > 0 && !d->travel)) return fail(EPI_ERR_BAD_ARGUMENT, "grid: null grid axis");
@@ -512,7 +605,32 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
     G->npad = npad;
 
     // seed-row variants: ToyConn.scaleRow(W, seedIdx, ts) touches only that row (Calibrate.scala:29)
-    {
+    if (G->graph.sparse) {
+        // the stored entries of the row in column order: scaling and the row-sum cap of scaleRow add
+        // and multiply the zeros of the other columns without changing anything
+        const int rs = G->graph.h_rowptr[d->seed_idx], deg = G->graph.h_rowptr[d->seed_idx + 1] - rs;
+        const int nt = d->n_travel > 0 ? d->n_travel : 1;
+        std::vector<double> hq((size_t)nt * (deg > 0 ? deg : 1), 0.0), hs((size_t)nt, 0.0), row((size_t)(deg > 0 ? deg : 1));
+        for (int k = 0; k < d->n_travel; ++k) {
+            if (!std::isfinite(d->travel[k]) || d->travel[k] < 0.0) return fail(EPI_ERR_BAD_ARGUMENT, "grid: travel scale %d = %g", k, d->travel[k]);
+            double s = 0.0;
+            for (int e = 0; e < deg; ++e) {
+                row[e] = G->graph.h_val[rs + e];
+                if (G->graph.h_col[rs + e] != d->seed_idx) { row[e] *= d->travel[k]; s += row[e]; }
+            }
+            const double cap = std::fmin(0.2, s);
+            if (s > cap && s > 0) {
+                const double sc = cap / s;
+                for (int e = 0; e < deg; ++e)
+                    if (G->graph.h_col[rs + e] != d->seed_idx) row[e] *= sc;
+            }
+            rc = GraphTables::normalise_sparse_row(row.data(), G->graph.h_col.data() + rs, deg, d->seed_idx, &hq[(size_t)k * deg], &hs[k]);
+            if (rc) return rc;
+        }
+        G->seed_deg = deg;
+        HIP_TRY(G->qseed.upload(hq));
+        HIP_TRY(G->sumw_seed.upload(hs));
+    } else {
         std::vector<double> hq((size_t)(d->n_travel > 0 ? d->n_travel : 1) * npad, 0.0), hs((size_t)(d->n_travel > 0 ? d->n_travel : 1), 0.0);
         std::vector<double> row((size_t)n);
         for (int k = 0; k < d->n_travel; ++k) {
@@ -714,7 +832,7 @@ EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, doub
     if (g_count == 0) return EPI_OK;
     HIP_TRY(hipSetDevice(g->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    int32_t rc = g->work.ensure(g_count, g->npad);
+    int32_t rc = g->work.ensure(g_count, g->npad, g->graph.sparse);
     if (rc) return rc;
     const int n = g->n, npad = g->npad;
 
@@ -742,9 +860,14 @@ EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, doub
     ea.seed_idx = g->seed_idx; ea.n_travel = g->n_travel; ea.g_begin = g_begin;
     ea.step_t_max = g->steps;  // world.stepOne(cfg.stepsPerEpoch), Calibrate.scala:70
     ea.validate = 1;
-    ea.q = g->graph.q.as<double>(); ea.sumw = g->graph.sumw.as<double>();
-    ea.qseed = g->qseed.as<double>(); ea.sumw_seed = g->sumw_seed.as<double>();
-    ea.qtop = g->graph.qtop.as<double>(); ea.qtop_seed = g->qtop_seed.as<double>();
+    g->graph.fill(ea);
+    ea.sumw_seed = g->sumw_seed.as<double>();
+    if (g->graph.sparse) {
+        ea.qval_seed = g->qseed.as<double>(); ea.seed_deg = g->seed_deg;
+        ea.exports = g->work.exports.as<int32_t>();
+    } else {
+        ea.qseed = g->qseed.as<double>(); ea.qtop_seed = g->qtop_seed.as<double>();
+    }
     ea.beta0 = g->beta0.as<double>(); ea.beta_rows = g->n_beta > 0 ? g->n_beta : 1;
     ea.cst = g->cst.as<double>();
     ea.actions = g->actions.as<int8_t>(); ea.act_t0 = 0;
@@ -823,8 +946,6 @@ EPI_API int32_t epi_calibrate_grid(const epi_grid_desc* desc, double* loss, int3
 // ================================================================================================
 static int32_t world_build(epi_world* Wd, const epi_world_desc* d) {
     if (d->n < 1 || d->batch < 1) return fail(EPI_ERR_BAD_ARGUMENT, "world: n = %d, batch = %d", d->n, d->batch);
-    if (d->n > kMaxDenseN)
-        return fail(EPI_ERR_BAD_ARGUMENT, "world: n = %d countries exceeds the %d the register-resident row kernel holds", d->n, kMaxDenseN);
     if (!d->pop || !d->env || !d->prof || d->seed_idx < 0 || d->seed_idx >= d->n) return fail(EPI_ERR_BAD_ARGUMENT, "world: null input or bad seed index");
     int32_t rc = check_base_state(d->base, "world");
     if (rc) return rc;
@@ -865,7 +986,7 @@ static int32_t world_build(epi_world* Wd, const epi_world_desc* d) {
     if (d->env_seeds) Wd->env_seeds.assign(d->env_seeds, d->env_seeds + n);
     Wd->env_rnd.clear();
     for (int c = 0; c < n; ++c) Wd->env_rnd.emplace_back((int64_t)Wd->env_seeds[c]);
-    rc = Wd->work.ensure(d->batch, npad);
+    rc = Wd->work.ensure(d->batch, npad, Wd->graph.sparse);
     if (rc) return rc;
     const size_t cells = (size_t)d->batch * npad;
     HIP_TRY(Wd->act_dev.ensure(cells));
@@ -1017,9 +1138,9 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
     ea.t_begin = 0; ea.t_end = 1;
     ea.step_t_max = t_max;
     ea.validate = w->validate;
-    ea.q = w->graph.q.as<double>(); ea.sumw = w->graph.sumw.as<double>();
-    ea.qseed = nullptr; ea.sumw_seed = nullptr;
-    ea.qtop = w->graph.qtop.as<double>(); ea.qtop_seed = nullptr;
+    w->graph.fill(ea);
+    ea.qseed = nullptr; ea.sumw_seed = nullptr; ea.qtop_seed = nullptr; ea.qval_seed = nullptr;
+    if (w->graph.sparse) ea.exports = w->work.exports.as<int32_t>();
     ea.beta0 = w->beta0.as<double>(); ea.beta_rows = 1;
     ea.cst = w->cst.as<double>();
     ea.actions = nullptr; ea.act_episode = w->act_dev.as<int8_t>();

@@ -213,8 +213,229 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sparse (CSR) episode kernel for graphs too wide for the dense kernel.  One workgroup of 1024
+// threads = one episode; compartments live in HBM and are streamed once per phase; the two
+// inflow accumulators movedS/movedI for all n patches live in LDS (8 bytes per patch).
+//
+// Mobility (WorldToy.scala:106-126): a 16-lane group owns one row of the graph.  Entries that
+// are not stored have weight 0, hence raw = 0, base = 0 and fraction 0: they can only receive a
+// unit after every positive fraction has one.  For finite non-negative weights
+// rem = E - sum(base) never exceeds the number of positive fractions (rem equals the sum of the
+// fractions up to a rounding error far below 1, and every fraction is below 1), so the units
+// go to stored entries only; the kernel checks this and reports EPI_ERR_UNSUPPORTED otherwise.
+// Among the stored entries the stable descending order is computed directly:
+// rank(j) = #{k : f_k > f_j} + #{k < j : f_k == f_j}; entry j gets a unit iff rank(j) < rem.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t group_sum16(uint32_t v) {  // sum over a 16-lane DPP row, in every lane
+    v += dpp_or<0xB1, 0xf>(0u, v);
+    v += dpp_or<0x4E, 0xf>(0u, v);
+    v += dpp_or<0x141, 0xf>(0u, v);
+    v += dpp_or<0x140, 0xf>(0u, v);
+    return v;
+}
+
+template <int R>
+__device__ __forceinline__ void group_apportion(int32_t E, int deg, const double* __restrict__ qv,
+                                                const int32_t* __restrict__ cols, int diag, uint32_t* sh_mov, int gl,
+                                                int* sh_err, int t) {
+    const double Ed = (double)E;
+    double fr[R];
+    uint32_t base[R], rank[R];
+    uint32_t bsum = 0, pos = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int k = r * 16 + gl;
+        const double raw = (k < deg ? qv[k] : 0.0) * Ed;
+        base[r] = (uint32_t)(int32_t)raw;
+        fr[r] = frac_of(raw);
+        bsum += base[r];
+        pos += (fr[r] > 0.0);
+        rank[r] = 0u;
+    }
+    const int32_t rem = (int32_t)((uint32_t)E - group_sum16(bsum));
+    if (rem > 0) {
+        if (rem > (int32_t)group_sum16(pos)) record_error(sh_err, EPI_ERR_UNSUPPORTED, diag, t);
+        for (int k2 = 0; k2 < deg; ++k2) {
+            const double f2 = frac_of(qv[k2] * Ed);
+#pragma unroll
+            for (int r = 0; r < R; ++r) rank[r] += (f2 > fr[r]) || (f2 == fr[r] && k2 < r * 16 + gl);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int k = r * 16 + gl;
+        if (k < deg) {
+            const uint32_t alloc = base[r] + (uint32_t)(rem > 0 && fr[r] > 0.0 && (int32_t)rank[r] < rem);
+            const int col = cols[k];
+            if (alloc != 0u && col != diag) atomicAdd(&sh_mov[col], alloc);
+        }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(1024) void episode_csr_kernel(const EpisodeArgs a) {
+    extern __shared__ __align__(16) unsigned char sh_raw[];
+    const int n = a.n;
+    uint32_t* sh_movS = reinterpret_cast<uint32_t*>(sh_raw);
+    uint32_t* sh_movI = sh_movS + n;
+    unsigned long long* sh_mass = reinterpret_cast<unsigned long long*>(sh_raw + (((size_t)n * 8 + 15) & ~(size_t)15));
+    int* sh_err = reinterpret_cast<int*>(sh_mass + 4);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int e = blockIdx.x;
+    const int g = a.g_begin + e;
+    const int ti = a.n_travel > 0 ? g % a.n_travel : 0;
+    int bi = a.n_travel > 0 ? g / a.n_travel : g;
+    bi = bi < a.beta_rows ? bi : a.beta_rows - 1;
+    const int NP = a.npad;
+    const size_t eoff = (size_t)e * NP;
+    const size_t plane = (size_t)a.count * NP;
+    int32_t* __restrict__ st_s = a.st + 0 * plane + eoff;
+    int32_t* __restrict__ st_i = a.st + 1 * plane + eoff;
+    int32_t* __restrict__ st_r = a.st + 2 * plane + eoff;
+    int32_t* __restrict__ st_d = a.st + 3 * plane + eoff;
+    int32_t* __restrict__ st_v = a.st + 4 * plane + eoff;
+    int32_t* __restrict__ expS = a.exports + 0 * plane + eoff;
+    int32_t* __restrict__ expI = a.exports + 1 * plane + eoff;
+
+    if (tid == 0) {
+        sh_mass[0] = sh_mass[1] = sh_mass[2] = sh_mass[3] = 0ull;
+        sh_err[0] = sh_err[1] = sh_err[2] = sh_err[3] = 0;
+    }
+    __syncthreads();
+
+    for (int t = a.t_begin; t < a.t_end; ++t) {
+        const int par = t & 1;
+        // ------------------------------------------------------------------ phase A: local dynamics
+        unsigned long long mass_local = 0ull;
+        for (int c = tid; c < n; c += 1024) {
+            StepConsts k;
+            k.beta0 = a.beta0[(size_t)bi * NP + c];
+            k.gamma = a.cst[CST_GAMMA * NP + c];
+            k.ifr0 = a.cst[CST_IFR0 * NP + c];
+            k.cnoise = a.cst[CST_CNOISE * NP + c];
+            k.eff1 = a.cst[CST_EFF1 * NP + c];
+            k.eff2 = a.cst[CST_EFF2 * NP + c];
+            k.eff3 = a.cst[CST_EFF3 * NP + c];
+            k.surge = a.cst[CST_SURGE * NP + c];
+            k.vax6 = a.cst[CST_VAX6 * NP + c];
+            k.vax7 = a.cst[CST_VAX7 * NP + c];
+            int act = a.act_episode ? (int)a.act_episode[eoff + c] : (int)a.actions[(size_t)(t - a.act_t0) * NP + c];
+            act = act < 0 ? 0 : (act > 7 ? 7 : act);
+            const double z = a.noise_episode ? a.noise_episode[eoff + c] : a.noise[(size_t)(t - a.noise_t0) * NP + c];
+            const int32_t s0 = st_s[c], i0 = st_i[c], r0 = st_r[c], d0 = st_d[c], v0 = st_v[c];
+            const int32_t tc = a.tcur[eoff + c];
+            const long long tb = (long long)s0 + i0 + r0 + d0 + v0;
+            const LocalOut o = local_step(k, s0, i0, r0, d0, v0, a.cap[eoff + c], act, z);
+            const long long ta = (long long)o.s + o.i + o.r + o.d + o.v;
+            if (a.validate && ta != tb) record_error(sh_err, EPI_ERR_LOCAL_MASS, c, tc);
+            if ((o.s | o.i | o.r | o.d | o.v) < 0) record_error(sh_err, EPI_ERR_INT_RANGE, c, tc);
+            if (a.rwd) a.reward_out[eoff + c] = reward_of(a.rwd[c], (double)i0, (double)d0, o, act);
+            st_s[c] = o.s; st_i[c] = o.i; st_r[c] = o.r; st_d[c] = o.d; st_v[c] = o.v;
+            a.cap[eoff + c] = o.cap;
+            a.tcur[eoff + c] = tc + 1;
+            const double sw = (c == a.seed_idx && a.qval_seed) ? a.sumw_seed[ti] : a.sumw[c];
+            expS[c] = export_count(max(0, o.s), sw);
+            expI[c] = export_count(max(0, o.i), sw);
+            sh_movS[c] = 0u;
+            sh_movI[c] = 0u;
+            mass_local += ta > 0 ? (unsigned long long)ta : 0ull;
+        }
+        if (a.validate) {
+            // per-thread partial sums stay below 2^44 (at most 20 patches of < 2^34 each per thread)
+            const unsigned long long wsum = wave_sum_u64(mass_local);
+            if (lane == 0) atomicAdd(&sh_mass[par * 2 + 0], wsum);
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------------------ phase B: mobility
+        if (tid == 0 && a.validate && t > a.t_begin) {
+            const int p = (t - 1) & 1;
+            if (sh_mass[p * 2] != sh_mass[p * 2 + 1]) record_error(sh_err, EPI_ERR_WORLD_MASS, -1, t - 1);
+            sh_mass[p * 2] = 0ull;
+            sh_mass[p * 2 + 1] = 0ull;
+        }
+        {
+            const int grp = tid >> 4, gl = tid & 15;
+            for (int row = grp; row < n; row += 64) {
+                const int32_t ES = expS[row], EI = expI[row];
+                if ((ES | EI) == 0) continue;
+                const int rs = a.rowptr[row];
+                const int deg = a.rowptr[row + 1] - rs;
+                const double* __restrict__ qv =
+                    (row == a.seed_idx && a.qval_seed) ? a.qval_seed + (size_t)ti * a.seed_deg : a.qval + rs;
+                const int32_t* __restrict__ cols = a.col + rs;
+                if (ES > 0) group_apportion<R>(ES, deg, qv, cols, row, sh_movS, gl, sh_err, t);
+                if (EI > 0) group_apportion<R>(EI, deg, qv, cols, row, sh_movI, gl, sh_err, t);
+            }
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------------------ phase C: apply
+        unsigned long long mass_move = 0ull;
+        for (int c = tid; c < n; c += 1024) {
+            const int32_t movedS = (int32_t)(sh_movS[c] - (uint32_t)expS[c]);
+            const int32_t movedI = (int32_t)(sh_movI[c] - (uint32_t)expI[c]);
+            const double ns = fmax(0.0, (double)st_s[c] + (double)movedS);
+            const double ni = fmax(0.0, (double)st_i[c] + (double)movedI);
+            const int32_t tc = a.tcur[eoff + c];
+            if (ns > 2147483647.0 || ni > 2147483647.0) record_error(sh_err, EPI_ERR_INT_RANGE, c, tc);
+            const int32_t s3 = (int32_t)ns, i3 = (int32_t)ni;
+            st_s[c] = s3;
+            st_i[c] = i3;
+            a.tcur[eoff + c] = min(tc + 1, a.step_t_max);
+            if (a.arrival[eoff + c] < 0 && i3 >= 10) a.arrival[eoff + c] = t;
+            if (i3 > a.peak[eoff + c]) a.peak[eoff + c] = i3;
+            if (a.flow_s) {
+                a.flow_s[eoff + c] = movedS;
+                a.flow_i[eoff + c] = movedI;
+            }
+            const long long tm = (long long)s3 + i3 + st_r[c] + st_d[c] + st_v[c];
+            mass_move += tm > 0 ? (unsigned long long)tm : 0ull;
+        }
+        if (a.validate) {
+            const unsigned long long wsum = wave_sum_u64(mass_move);
+            if (lane == 0) atomicAdd(&sh_mass[par * 2 + 1], wsum);
+        }
+        // patch c is read here and re-initialised in the next phase A by the same thread: no barrier
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (a.validate && a.t_end > a.t_begin) {
+            const int p = (a.t_end - 1) & 1;
+            if (sh_mass[p * 2] != sh_mass[p * 2 + 1]) record_error(sh_err, EPI_ERR_WORLD_MASS, -1, a.t_end - 1);
+        }
+        if (sh_err[0] != 0 && a.err[e * 4] == 0) {
+            a.err[e * 4 + 1] = sh_err[1];
+            a.err[e * 4 + 2] = sh_err[2];
+            a.err[e * 4] = sh_err[0];
+        }
+    }
+}
+
+size_t csr_lds_bytes(int n) { return (((size_t)n * 8 + 15) & ~(size_t)15) + 4 * sizeof(unsigned long long) + 4 * sizeof(int); }
+
+template <int R>
+static hipError_t launch_csr(const EpisodeArgs& a, hipStream_t s) {
+    const size_t lds = csr_lds_bytes(a.n);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&episode_csr_kernel<R>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(episode_csr_kernel<R>, dim3((unsigned)a.count), dim3(1024), lds, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_episode(const EpisodeArgs& a, hipStream_t s) {
     if (a.count <= 0 || a.t_end <= a.t_begin) return hipSuccess;
+    if (a.rowptr) {
+        if (csr_lds_bytes(a.n) > kMaxLdsBytes) return hipErrorInvalidValue;
+        if (a.max_deg <= 16) return launch_csr<1>(a, s);
+        if (a.max_deg <= 32) return launch_csr<2>(a, s);
+        if (a.max_deg <= 64) return launch_csr<4>(a, s);
+        return hipErrorInvalidValue;
+    }
     const dim3 grid((unsigned)a.count);
     switch (a.npad / 64) {
         case 1: hipLaunchKernelGGL(episode_dense_kernel<1>, grid, dim3(64), 0, s, a); break;

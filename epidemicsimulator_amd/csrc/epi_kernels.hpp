@@ -10,6 +10,9 @@ namespace epi {
 
 constexpr int kMaxDenseR = 16;               // register slots per lane in the dense row kernel
 constexpr int kMaxDenseN = kMaxDenseR * 64;  // widest dense row held in one wave's registers
+constexpr size_t kMaxLdsBytes = 160 * 1024;  // LDS of one CU: bounds the patches of a sparse world
+constexpr int kMaxSparseDegree = 64;          // longest stored row the sparse kernel apportions
+size_t csr_lds_bytes(int n);
 
 // Indices into the per-country constant table cst[k][npad] (StepConsts minus beta0).
 enum { CST_GAMMA = 0, CST_IFR0, CST_CNOISE, CST_EFF1, CST_EFF2, CST_EFF3, CST_SURGE, CST_VAX6, CST_VAX7, CST_COUNT };
@@ -27,6 +30,13 @@ struct EpisodeArgs {
     const double* sumw;      // [npad]     max(0, sum_j wRow_j)  (WorldToy.scala:114)
     const double* qseed;     // [n_travel][npad] seed-row variants (ToyConn.scaleRow per travel scale)
     const double* sumw_seed; // [n_travel]
+    // sparse graphs (rowptr != NULL): CSR rows of normalised weights instead of q
+    const int32_t* rowptr;   // [n+1]
+    const int32_t* col;      // [nnz] ascending inside a row
+    const double* qval;      // [nnz] w_ij / sumW_i (a stored diagonal entry holds 0)
+    const double* qval_seed; // [n_travel][seed_deg] seed-row variants
+    int seed_deg, max_deg;
+    int32_t* exports;        // [2][count][npad] exportS / exportI scratch of the sparse kernel
     const double* qtop;      // [n][kTopWeights] each row's largest normalised weights, descending (or NULL)
     const double* qtop_seed; // [n_travel][kTopWeights]
     const double* beta0;     // [n_beta][npad] or [1][npad]

@@ -37,7 +37,8 @@ typedef enum epi_status {
     EPI_ERR_LOCAL_MASS = 3,   /* "mass not conserved (local)"           WorldToy.scala:94  */
     EPI_ERR_WORLD_MASS = 4,   /* "global mass changed during mobility"  WorldToy.scala:144 */
     EPI_ERR_ASSERT_STATE = 5, /* Validation.assertState                 Validation.scala:6-11 */
-    EPI_ERR_INT_RANGE = 6     /* a compartment left the Int range the reference computes in */
+    EPI_ERR_INT_RANGE = 6,    /* a compartment left the Int range the reference computes in */
+    EPI_ERR_UNSUPPORTED = 7   /* an input outside what the kernels implement (message says which) */
 } epi_status;
 
 /* Geo.Country fields read by EpidemicEnv (Geo.scala:4-21; env.scala:59-101,142-234). */

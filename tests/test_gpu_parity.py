@@ -313,3 +313,69 @@ def test_grid_full_size_properties(epi):
     np.testing.assert_array_equal(got["arrival"], want["arrival"])
     np.testing.assert_array_equal(got["peak"], want["peak"])
     np.testing.assert_allclose(got["loss"], want["loss"], rtol=1e-12, atol=0)
+
+
+# ---------------------------------------------------------------- sparse (CSR) worlds, n > 1024
+def _sparse_workload(n, deg, nb, nt, steps, seed):
+    from epidemicsimulator_amd import synth
+    countries, xy = synth.make_countries(n, seed)
+    wl = synth.small_workload(8, nb, nt, steps, seed=seed)
+    wl["countries"], wl["profiles"] = countries, countries
+    wl["conn"] = synth.gravity_csr(countries, xy, seed, mean_degree=deg)
+    wl["t_arrive"], wl["t_peak"] = synth.targets(n, steps, seed)
+    return wl
+
+
+@pytest.mark.parametrize("n,deg,nb,nt,steps,eps", [(1300, 6.0, 1, 2, 14, 1.0), (1100, 14.0, 2, 1, 10, 0.4), (2100, 3.0, 1, 1, 8, 1.0)])
+def test_grid_sparse_matches_oracle(epi, n, deg, nb, nt, steps, eps):
+    """Worlds wider than the dense kernel run on the CSR kernel; eps < 1 makes argmax-Q steps frequent."""
+    from epidemicsimulator_amd import synth
+    wl = _sparse_workload(n, deg, nb, nt, steps, seed=300 + n)
+    base = synth.base_state(steps)
+    hp = epi.HyperParams(epsilon_start=eps, epsilon_end=eps)
+    got = util.engine_grid(wl, base, True, hp=hp)
+    ohp = O.default_hyper(); ohp.epsilon_start = eps; ohp.epsilon_end = eps
+    nn = len(wl["countries"])
+    ta = np.zeros(nn); tp = np.zeros(nn); ha = np.ones(nn, dtype=np.uint8)
+    for c, v in wl["t_arrive"].items():
+        ta[c] = v
+    for c, v in wl["t_peak"].items():
+        tp[c] = v
+    want = O.grid_surface([c.pop for c in wl["countries"]], util.dense_of(wl["conn"], nn), 0, util.oracle_state(base),
+                          [util.prof_dict(p) for p in wl["profiles"]], steps, wl["betas"], wl["travel"], ta, ha, tp, ha, True, hp=ohp)
+    util.assert_grid_equal(got, want)
+
+
+def test_world_sparse_step_given_actions(epi):
+    from epidemicsimulator_amd import synth
+    n = 1200
+    countries, xy = synth.make_countries(n, 77)
+    conn = synth.gravity_csr(countries, xy, 77, mean_degree=9.0)
+    w, ow, rng = _world_pair(epi, countries, conn, batch=2)
+    for step in range(6):
+        acts = rng.integers(0, 8, (2, n)); gauss = rng.normal(size=(2, n))
+        acts[1], gauss[1] = acts[0], gauss[0]
+        states, rewards = w.step_actions(acts, gauss, 120)
+        o_r, o_ms, o_mi = ow.step_given(acts[0], gauss[0], 120)
+        o_states = ow.states()
+        assert ow.error()[0] == 0
+        for b in range(2):
+            for c in range(n):
+                g = states[b][c]
+                assert (g.s, g.i, g.r, g.d, g.v, g.hosp_cap, g.t) == o_states[c].tup(), "step %d country %d" % (step, c)
+            np.testing.assert_array_equal(rewards[b], o_r)
+        ms, mi = w.last_flows()
+        np.testing.assert_array_equal(ms[0], o_ms)
+        np.testing.assert_array_equal(mi[1], o_mi)
+
+
+def test_sparse_limits_are_reported(epi):
+    from epidemicsimulator_amd import synth
+    countries, xy = synth.make_countries(1100, 5)
+    dense = synth.gravity_dense(countries, xy)          # 1099 stored weights per row: too wide for the CSR kernel
+    wl = synth.small_workload(8, 1, 1, 3)
+    wl["countries"], wl["profiles"], wl["conn"] = countries, countries, dense
+    wl["t_arrive"], wl["t_peak"] = {}, {}
+    with pytest.raises(epi.EpiError) as ei:
+        util.engine_grid(wl, synth.base_state(3))
+    assert "per row" in str(ei.value)
