@@ -168,8 +168,10 @@ struct GraphTables {
     std::vector<double> W;  // dense host copy (seed-row variants are derived from it)
     // sparse mode (n > kMaxDenseN): CSR arrays on the device, raw weights on the host
     bool sparse = false;
-    int max_deg = 0;
-    DevBuf d_rowptr, d_col, d_qval;
+    int max_deg = 0, lane_deg = 0;
+    DevBuf d_rowptr, d_col, d_qval, d_slots, d_off, d_long_rows, d_long_q, d_long_col;
+    std::vector<int32_t> h_long_rows;     // rows longer than kLaneSlots
+    std::vector<int32_t> h_slots, h_off;  // ELL block tables
     std::vector<int32_t> h_rowptr, h_col;
     std::vector<double> h_val;
 
@@ -237,10 +239,52 @@ struct GraphTables {
             if (pop_[c] < 0) return fail(EPI_ERR_BAD_ARGUMENT, "pop[%d] = %d is negative", c, pop_[c]);
             hp[c] = pop_[c];
         }
-        if (h_col.empty()) h_col.push_back(0);
+        // slot-major blocks of 64 rows: one lane per row reads its k-th weight with a coalesced load
+        const int nblocks = (n + 63) / 64;
+        h_slots.assign((size_t)nblocks, 0);
+        h_off.assign((size_t)nblocks, 0);
+        int total_slots = 0;
+        h_long_rows.clear();
+        for (int i = 0; i < n; ++i)
+            if (h_rowptr[i + 1] - h_rowptr[i] > kLaneSlots) h_long_rows.push_back(i);
+        lane_deg = 0;
+        for (int b = 0; b < nblocks; ++b) {
+            int dmax = 0;
+            for (int i = b * 64; i < std::min(n, b * 64 + 64); ++i) {
+                const int deg = h_rowptr[i + 1] - h_rowptr[i];
+                if (deg <= kLaneSlots) dmax = std::max(dmax, deg);
+            }
+            lane_deg = std::max(lane_deg, dmax);
+            h_slots[b] = dmax;
+            h_off[b] = total_slots;
+            total_slots += dmax;
+        }
+        std::vector<double> eq((size_t)(total_slots > 0 ? total_slots : 1) * 64, 0.0);
+        std::vector<int32_t> ec((size_t)(total_slots > 0 ? total_slots : 1) * 64, -1);
+        for (int i = 0; i < n; ++i) {
+            const int b = i / 64, l = i % 64, rs = h_rowptr[i], deg = h_rowptr[i + 1] - rs;
+            if (deg > kLaneSlots) continue;  // long rows stay empty in the lane layout
+            for (int k = 0; k < deg; ++k) {
+                eq[((size_t)h_off[b] + k) * 64 + l] = hq[rs + k];
+                ec[((size_t)h_off[b] + k) * 64 + l] = h_col[rs + k];
+            }
+        }
+        const size_t nl = h_long_rows.size();
+        std::vector<double> lq((nl ? nl : 1) * 64, 0.0);
+        std::vector<int32_t> lc((nl ? nl : 1) * 64, -1), lr(h_long_rows);
+        for (size_t o = 0; o < nl; ++o) {
+            const int i = h_long_rows[o], rs = h_rowptr[i], deg = h_rowptr[i + 1] - rs;
+            for (int k = 0; k < deg; ++k) { lq[o * 64 + k] = hq[rs + k]; lc[o * 64 + k] = h_col[rs + k]; }
+        }
+        if (lr.empty()) lr.push_back(0);
+        HIP_TRY(d_long_rows.upload(lr));
+        HIP_TRY(d_long_q.upload(lq));
+        HIP_TRY(d_long_col.upload(lc));
         HIP_TRY(d_rowptr.upload(h_rowptr));
-        HIP_TRY(d_col.upload(h_col));
-        HIP_TRY(d_qval.upload(hq));
+        HIP_TRY(d_slots.upload(h_slots));
+        HIP_TRY(d_off.upload(h_off));
+        HIP_TRY(d_col.upload(ec));
+        HIP_TRY(d_qval.upload(eq));
         HIP_TRY(sumw.upload(hs));
         HIP_TRY(pop.upload(hp));
         return EPI_OK;
@@ -251,7 +295,10 @@ struct GraphTables {
         if (sparse) {
             ea.q = nullptr; ea.qtop = nullptr;
             ea.rowptr = d_rowptr.as<int32_t>(); ea.col = d_col.as<int32_t>(); ea.qval = d_qval.as<double>();
-            ea.max_deg = max_deg;
+            ea.ell_slots = d_slots.as<int32_t>(); ea.ell_off = d_off.as<int32_t>();
+            ea.max_deg = lane_deg;
+            ea.n_long = (int)h_long_rows.size();
+            ea.long_rows = d_long_rows.as<int32_t>(); ea.long_q = d_long_q.as<double>(); ea.long_col = d_long_col.as<int32_t>();
         } else {
             ea.q = q.as<double>(); ea.qtop = qtop.as<double>();
             ea.rowptr = nullptr;
@@ -382,7 +429,7 @@ int32_t assert_initial(const epi_state& b) {
 // ================================================================================================
 struct epi_grid {
     int device = 0;
-    int n = 0, npad = 0, steps = 0, n_beta = 0, n_travel = 0, seed_idx = 0, seed_deg = 0;
+    int n = 0, npad = 0, steps = 0, n_beta = 0, n_travel = 0, seed_idx = 0, seed_deg = 0, seed_long = 0;
     epi_state base{};
     GraphTables graph;
     DevBuf qseed, sumw_seed, qtop_seed, beta0, cst, actions, noise;
@@ -610,7 +657,11 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
         // and multiply the zeros of the other columns without changing anything
         const int rs = G->graph.h_rowptr[d->seed_idx], deg = G->graph.h_rowptr[d->seed_idx + 1] - rs;
         const int nt = d->n_travel > 0 ? d->n_travel : 1;
-        std::vector<double> hq((size_t)nt * (deg > 0 ? deg : 1), 0.0), hs((size_t)nt, 0.0), row((size_t)(deg > 0 ? deg : 1));
+        const bool seed_long = deg > kLaneSlots;
+        // the lane of the seed row reads its block's slots; a long seed row is read as 64 padded slots
+        const int slots = seed_long ? 64 : std::max(1, G->graph.h_slots[d->seed_idx / 64]);
+        G->seed_long = seed_long ? 1 : 0;
+        std::vector<double> hq((size_t)nt * slots, 0.0), hs((size_t)nt, 0.0), row((size_t)(deg > 0 ? deg : 1));
         for (int k = 0; k < d->n_travel; ++k) {
             if (!std::isfinite(d->travel[k]) || d->travel[k] < 0.0) return fail(EPI_ERR_BAD_ARGUMENT, "grid: travel scale %d = %g", k, d->travel[k]);
             double s = 0.0;
@@ -624,10 +675,10 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
                 for (int e = 0; e < deg; ++e)
                     if (G->graph.h_col[rs + e] != d->seed_idx) row[e] *= sc;
             }
-            rc = GraphTables::normalise_sparse_row(row.data(), G->graph.h_col.data() + rs, deg, d->seed_idx, &hq[(size_t)k * deg], &hs[k]);
+            rc = GraphTables::normalise_sparse_row(row.data(), G->graph.h_col.data() + rs, deg, d->seed_idx, &hq[(size_t)k * slots], &hs[k]);
             if (rc) return rc;
         }
-        G->seed_deg = deg;
+        G->seed_deg = slots;
         HIP_TRY(G->qseed.upload(hq));
         HIP_TRY(G->sumw_seed.upload(hs));
     } else {
@@ -863,7 +914,7 @@ EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, doub
     g->graph.fill(ea);
     ea.sumw_seed = g->sumw_seed.as<double>();
     if (g->graph.sparse) {
-        ea.qval_seed = g->qseed.as<double>(); ea.seed_deg = g->seed_deg;
+        ea.qval_seed = g->qseed.as<double>(); ea.seed_deg = g->seed_deg; ea.seed_long = g->seed_long;
         ea.exports = g->work.exports.as<int32_t>();
     } else {
         ea.qseed = g->qseed.as<double>(); ea.qtop_seed = g->qtop_seed.as<double>();
@@ -873,6 +924,7 @@ EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, doub
     ea.actions = g->actions.as<int8_t>(); ea.act_t0 = 0;
     ea.noise = g->noise.as<double>(); ea.noise_t0 = 0;
     ea.st = ia.st; ea.cap = ia.cap; ea.tcur = ia.tcur; ea.arrival = ia.arrival; ea.peak = ia.peak; ea.err = ia.err;
+    if (getenv("EPI_DEBUG")) { ea.debug = atoi(getenv("EPI_DEBUG")); ea.validate = 0; }
     if (getenv("EPI_STATS")) {
         if (!g->stats.p) {
             HIP_TRY(g->stats.ensure(64 * sizeof(unsigned long long)));

@@ -214,67 +214,110 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
 }
 
 // ---------------------------------------------------------------------------------------------
-// Sparse (CSR) episode kernel for graphs too wide for the dense kernel.  One workgroup of 1024
-// threads = one episode; compartments live in HBM and are streamed once per phase; the two
-// inflow accumulators movedS/movedI for all n patches live in LDS (8 bytes per patch).
+// Sparse episode kernel for graphs too wide for the dense kernel.  One workgroup of 512 threads =
+// one episode; compartments live in HBM and are streamed once per phase; the two inflow
+// accumulators movedS/movedI for all n patches live in LDS (8 bytes per patch).
 //
-// Mobility (WorldToy.scala:106-126): a 16-lane group owns one row of the graph.  Entries that
-// are not stored have weight 0, hence raw = 0, base = 0 and fraction 0: they can only receive a
-// unit after every positive fraction has one.  For finite non-negative weights
+// Mobility (WorldToy.scala:106-126): ONE LANE owns one row.  Rows are stored in blocks of 64 in a
+// slot-major (ELL) layout -- slot k of the 64 rows of a block is contiguous -- so that the 64 lanes
+// of a wave read their k-th weights with one coalesced load.  Every lane runs the same
+// largest-remainder split as the dense kernel on its own short row, entirely in its registers:
+// high words of the fractions as keys, a threshold K with #{key >= K} = rem found by bracketing,
+// ties in the high word finished exactly on the full fractions in ascending column order.
+//
+// Entries that are not stored have weight 0, hence raw = 0, base = 0 and fraction 0: they could only
+// receive a unit after every positive fraction has one.  For finite non-negative weights
 // rem = E - sum(base) never exceeds the number of positive fractions (rem equals the sum of the
-// fractions up to a rounding error far below 1, and every fraction is below 1), so the units
-// go to stored entries only; the kernel checks this and reports EPI_ERR_UNSUPPORTED otherwise.
-// Among the stored entries the stable descending order is computed directly:
-// rank(j) = #{k : f_k > f_j} + #{k < j : f_k == f_j}; entry j gets a unit iff rank(j) < rem.
+// fractions up to a rounding error far below 1, and every fraction is below 1), so the units go
+// to stored entries only; the kernel checks this and reports EPI_ERR_UNSUPPORTED otherwise.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t group_sum16(uint32_t v) {  // sum over a 16-lane DPP row, in every lane
-    v += dpp_or<0xB1, 0xf>(0u, v);
-    v += dpp_or<0x4E, 0xf>(0u, v);
-    v += dpp_or<0x141, 0xf>(0u, v);
-    v += dpp_or<0x140, 0xf>(0u, v);
-    return v;
-}
+constexpr int kCsrThreads = 512;  // 8 waves: room for a whole row of keys per lane without spilling
 
-template <int R>
-__device__ __forceinline__ void group_apportion(int32_t E, int deg, const double* __restrict__ qv,
-                                                const int32_t* __restrict__ cols, int diag, uint32_t* sh_mov, int gl,
-                                                int* sh_err, int t) {
+template <int DMAX>
+__device__ __forceinline__ void lane_apportion(int32_t E, int D, const double* __restrict__ qp, int qstride,
+                                               const int32_t* __restrict__ cp, int row, uint32_t* sh_mov, int* sh_err,
+                                               int t) {
     const double Ed = (double)E;
-    double fr[R];
-    uint32_t base[R], rank[R];
-    uint32_t bsum = 0, pos = 0;
+    uint32_t key[DMAX];
+    uint32_t bsum = 0u, pos = 0u, kmax = 0u;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int k = r * 16 + gl;
-        const double raw = (k < deg ? qv[k] : 0.0) * Ed;
-        base[r] = (uint32_t)(int32_t)raw;
-        fr[r] = frac_of(raw);
-        bsum += base[r];
-        pos += (fr[r] > 0.0);
-        rank[r] = 0u;
+    for (int k = 0; k < DMAX; ++k) {
+        key[k] = 0u;
+        if (k < D) {
+            const double raw = qp[(size_t)k * qstride] * Ed;
+            const double fr = frac_of(raw);
+            bsum += (uint32_t)(int32_t)raw;
+            key[k] = (uint32_t)__double2hiint(fr);
+            pos += (fr > 0.0);
+            kmax = max(kmax, key[k]);
+        }
     }
-    const int32_t rem = (int32_t)((uint32_t)E - group_sum16(bsum));
-    if (rem > 0) {
-        if (rem > (int32_t)group_sum16(pos)) record_error(sh_err, EPI_ERR_UNSUPPORTED, diag, t);
-        for (int k2 = 0; k2 < deg; ++k2) {
-            const double f2 = frac_of(qv[k2] * Ed);
+    int32_t rem = E > 0 ? (int32_t)((uint32_t)E - bsum) : 0;
+    if (rem > (int32_t)pos) {
+        record_error(sh_err, EPI_ERR_UNSUPPORTED, row, t);
+        rem = 0;
+    }
+    // per-lane bracket: #{key >= lo} = clo > rem > chi = #{key >= hi}; padding slots hold key 0 and
+    // every probe is >= 1, so they are never counted
+    uint32_t lo = 0u, hi = kmax + 1u, K = 0u;
+    int clo = D, chi = 0, it = 0;
+    bool found = false;
+    bool active = rem > 0;
+    while (active) {
+        uint32_t mid;
+        if ((it & 3) == 3) {
+            mid = lo + ((hi - lo) >> 1);
+        } else {
+            const float f = ((float)(clo - rem) + 0.5f) * __builtin_amdgcn_rcpf((float)(clo - chi + 1));
+            const double vlo = from_hi_word(lo), vhi = from_hi_word(hi);
+            mid = (uint32_t)__double2hiint(vlo + (vhi - vlo) * (double)f);
+        }
+        mid = max(mid, lo + 1u);
+        mid = min(mid, hi - 1u);
+        int c = 0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) rank[r] += (f2 > fr[r]) || (f2 == fr[r] && k2 < r * 16 + gl);
+        for (int k = 0; k < DMAX; ++k) c += (key[k] >= mid);
+        ++it;
+        if (c == rem) { found = true; K = mid; active = false; }
+        else if (c > rem) { lo = mid; clo = c; }
+        else { hi = mid; chi = c; }
+        if (hi - lo <= 1u) active = false;
+    }
+    // tie in the high word `lo`: pick m = rem - chi of its members by (fraction descending, column
+    // ascending), one at a time; members are few unless weights repeat
+    unsigned long long picked = 0ull;
+    const bool tie = rem > 0 && !found;
+    if (__any(tie)) {
+        int m = tie ? rem - chi : 0;
+        while (__any(m > 0)) {
+            double best = -1.0;
+            int best_k = -1;
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) {
+                if (k < D) {
+                    const double fr = frac_of(qp[(size_t)k * qstride] * Ed);
+                    const bool cand = m > 0 && key[k] == lo && !((picked >> k) & 1ull) && fr > best;
+                    if (cand) { best = fr; best_k = k; }
+                }
+            }
+            if (m > 0 && best_k >= 0) picked |= 1ull << best_k;
+            m -= 1;
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int k = r * 16 + gl;
-        if (k < deg) {
-            const uint32_t alloc = base[r] + (uint32_t)(rem > 0 && fr[r] > 0.0 && (int32_t)rank[r] < rem);
-            const int col = cols[k];
-            if (alloc != 0u && col != diag) atomicAdd(&sh_mov[col], alloc);
+    for (int k = 0; k < DMAX; ++k) {
+        if (k < D) {
+            const double raw = qp[(size_t)k * qstride] * Ed;
+            const bool sel = found ? (key[k] >= K) : (tie && (key[k] > lo || ((picked >> k) & 1ull)));
+            const uint32_t alloc = (uint32_t)(int32_t)raw + (uint32_t)sel;
+            const int col = cp[(size_t)k * 64];
+            if (E > 0 && alloc != 0u && col >= 0 && col != row) atomicAdd(&sh_mov[col], alloc);
         }
     }
 }
 
-template <int R>
-__global__ __launch_bounds__(1024) void episode_csr_kernel(const EpisodeArgs a) {
+template <int DMAX>
+__global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeArgs a) {
     extern __shared__ __align__(16) unsigned char sh_raw[];
     const int n = a.n;
     uint32_t* sh_movS = reinterpret_cast<uint32_t*>(sh_raw);
@@ -310,7 +353,7 @@ __global__ __launch_bounds__(1024) void episode_csr_kernel(const EpisodeArgs a) 
         const int par = t & 1;
         // ------------------------------------------------------------------ phase A: local dynamics
         unsigned long long mass_local = 0ull;
-        for (int c = tid; c < n; c += 1024) {
+        for (int c = tid; c < n; c += kCsrThreads) {
             StepConsts k;
             k.beta0 = a.beta0[(size_t)bi * NP + c];
             k.gamma = a.cst[CST_GAMMA * NP + c];
@@ -344,7 +387,7 @@ __global__ __launch_bounds__(1024) void episode_csr_kernel(const EpisodeArgs a) 
             mass_local += ta > 0 ? (unsigned long long)ta : 0ull;
         }
         if (a.validate) {
-            // per-thread partial sums stay below 2^44 (at most 20 patches of < 2^34 each per thread)
+            // per-thread partial sums stay below 2^44 (at most 40 patches of < 2^34 each per thread)
             const unsigned long long wsum = wave_sum_u64(mass_local);
             if (lane == 0) atomicAdd(&sh_mass[par * 2 + 0], wsum);
         }
@@ -358,24 +401,52 @@ __global__ __launch_bounds__(1024) void episode_csr_kernel(const EpisodeArgs a) 
             sh_mass[p * 2 + 1] = 0ull;
         }
         {
-            const int grp = tid >> 4, gl = tid & 15;
-            for (int row = grp; row < n; row += 64) {
-                const int32_t ES = expS[row], EI = expI[row];
+            const int wave = tid >> 6;
+            const int nblocks = (n + 63) >> 6;
+            for (int b = wave; b < nblocks; b += kCsrThreads / 64) {
+                const int row = b * 64 + lane;
+                // rows longer than kLaneSlots are empty in the lane layout and handled below
+                const bool valid = row < n && a.rowptr[row + 1] - a.rowptr[row] <= kLaneSlots;
+                const int32_t ES = valid ? expS[row] : 0, EI = valid ? expI[row] : 0;
+                if (!__any((ES | EI) != 0)) continue;
+                const int D = a.ell_slots[b];
+                const size_t off = (size_t)a.ell_off[b] * 64 + lane;
+                const double* __restrict__ qp = a.qval + off;
+                int qstride = 64;
+                if (row == a.seed_idx && a.qval_seed && !a.seed_long) {
+                    qp = a.qval_seed + (size_t)ti * a.seed_deg;
+                    qstride = 1;
+                }
+                const int32_t* __restrict__ cp = a.col + off;
+                if (a.debug & 1) continue;
+                if (__any(ES > 0)) lane_apportion<DMAX>(ES, D, qp, qstride, cp, row, sh_movS, sh_err, t);
+                if (__any(EI > 0)) lane_apportion<DMAX>(EI, D, qp, qstride, cp, row, sh_movI, sh_err, t);
+            }
+            // the few rows longer than kLaneSlots: one wave per row with the dense kernel's routine on
+            // the compact row (64 slots, zero padded), scattered through the row's column list
+            for (int o = wave; o < a.n_long; o += kCsrThreads / 64) {
+                const int row = a.long_rows[o];
+                const int32_t ES = __builtin_amdgcn_readfirstlane(expS[row]);
+                const int32_t EI = __builtin_amdgcn_readfirstlane(expI[row]);
                 if ((ES | EI) == 0) continue;
-                const int rs = a.rowptr[row];
-                const int deg = a.rowptr[row + 1] - rs;
-                const double* __restrict__ qv =
-                    (row == a.seed_idx && a.qval_seed) ? a.qval_seed + (size_t)ti * a.seed_deg : a.qval + rs;
-                const int32_t* __restrict__ cols = a.col + rs;
-                if (ES > 0) group_apportion<R>(ES, deg, qv, cols, row, sh_movS, gl, sh_err, t);
-                if (EI > 0) group_apportion<R>(EI, deg, qv, cols, row, sh_movI, gl, sh_err, t);
+                const int deg = a.rowptr[row + 1] - a.rowptr[row];
+                const double* __restrict__ qrow =
+                    (row == a.seed_idx && a.qval_seed) ? a.qval_seed + (size_t)ti * a.seed_deg : a.long_q + (size_t)o * 64;
+                const int col = a.long_col[(size_t)o * 64 + lane];
+                uint32_t accS[1] = {0u}, accI[1] = {0u};
+                if (ES > 0) apportion_row<1>(ES, deg, -1, qrow, accS, lane, nullptr);
+                if (EI > 0) apportion_row<1>(EI, deg, -1, qrow, accI, lane, nullptr);
+                if (col >= 0 && col != row) {
+                    if (accS[0]) atomicAdd(&sh_movS[col], accS[0]);
+                    if (accI[0]) atomicAdd(&sh_movI[col], accI[0]);
+                }
             }
         }
         __syncthreads();
 
         // ------------------------------------------------------------------ phase C: apply
         unsigned long long mass_move = 0ull;
-        for (int c = tid; c < n; c += 1024) {
+        for (int c = tid; c < n; c += kCsrThreads) {
             const int32_t movedS = (int32_t)(sh_movS[c] - (uint32_t)expS[c]);
             const int32_t movedI = (int32_t)(sh_movI[c] - (uint32_t)expI[c]);
             const double ns = fmax(0.0, (double)st_s[c] + (double)movedS);
@@ -417,13 +488,13 @@ __global__ __launch_bounds__(1024) void episode_csr_kernel(const EpisodeArgs a) 
 
 size_t csr_lds_bytes(int n) { return (((size_t)n * 8 + 15) & ~(size_t)15) + 4 * sizeof(unsigned long long) + 4 * sizeof(int); }
 
-template <int R>
+template <int DMAX>
 static hipError_t launch_csr(const EpisodeArgs& a, hipStream_t s) {
     const size_t lds = csr_lds_bytes(a.n);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&episode_csr_kernel<R>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&episode_csr_kernel<DMAX>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(episode_csr_kernel<R>, dim3((unsigned)a.count), dim3(1024), lds, s, a);
+    hipLaunchKernelGGL(episode_csr_kernel<DMAX>, dim3((unsigned)a.count), dim3(kCsrThreads), lds, s, a);
     return hipGetLastError();
 }
 
@@ -431,9 +502,8 @@ hipError_t launch_episode(const EpisodeArgs& a, hipStream_t s) {
     if (a.count <= 0 || a.t_end <= a.t_begin) return hipSuccess;
     if (a.rowptr) {
         if (csr_lds_bytes(a.n) > kMaxLdsBytes) return hipErrorInvalidValue;
-        if (a.max_deg <= 16) return launch_csr<1>(a, s);
-        if (a.max_deg <= 32) return launch_csr<2>(a, s);
-        if (a.max_deg <= 64) return launch_csr<4>(a, s);
+        if (a.max_deg <= 16) return launch_csr<16>(a, s);
+        if (a.max_deg <= kLaneSlots) return launch_csr<kLaneSlots>(a, s);
         return hipErrorInvalidValue;
     }
     const dim3 grid((unsigned)a.count);

@@ -12,6 +12,7 @@ constexpr int kMaxDenseR = 16;               // register slots per lane in the d
 constexpr int kMaxDenseN = kMaxDenseR * 64;  // widest dense row held in one wave's registers
 constexpr size_t kMaxLdsBytes = 160 * 1024;  // LDS of one CU: bounds the patches of a sparse world
 constexpr int kMaxSparseDegree = 64;          // longest stored row the sparse kernel apportions
+constexpr int kLaneSlots = 32;                // longest row a single lane keeps in registers
 size_t csr_lds_bytes(int n);
 
 // Indices into the per-country constant table cst[k][npad] (StepConsts minus beta0).
@@ -30,12 +31,20 @@ struct EpisodeArgs {
     const double* sumw;      // [npad]     max(0, sum_j wRow_j)  (WorldToy.scala:114)
     const double* qseed;     // [n_travel][npad] seed-row variants (ToyConn.scaleRow per travel scale)
     const double* sumw_seed; // [n_travel]
-    // sparse graphs (rowptr != NULL): CSR rows of normalised weights instead of q
-    const int32_t* rowptr;   // [n+1]
-    const int32_t* col;      // [nnz] ascending inside a row
-    const double* qval;      // [nnz] w_ij / sumW_i (a stored diagonal entry holds 0)
-    const double* qval_seed; // [n_travel][seed_deg] seed-row variants
-    int seed_deg, max_deg;
+    // sparse graphs (rowptr != NULL): rows in blocks of 64, slot-major (ELL) inside a block: slot k of
+    // row 64*b + l is element (ell_off[b] + k) * 64 + l of col / qval; ell_slots[b] = longest row of the block
+    const int32_t* rowptr;    // [n+1] (marks sparse mode; row lengths)
+    const int32_t* ell_slots; // [ceil(n/64)]
+    const int32_t* ell_off;   // [ceil(n/64)]
+    const int32_t* col;       // ELL columns, ascending inside a row, -1 = padding
+    const double* qval;       // ELL normalised weights w_ij / sumW_i (a stored diagonal entry holds 0)
+    const double* qval_seed;  // [n_travel][seed_deg] seed-row variants, zero padded to the block's slots
+    int seed_deg, max_deg;    // stride of qval_seed; longest row held in the lane layout
+    int seed_long;            // the seed row is one of the long rows below
+    int n_long;               // rows longer than kLaneSlots: compact copies, 64 slots each
+    const int32_t* long_rows; // [n_long]
+    const double* long_q;     // [n_long][64]
+    const int32_t* long_col;  // [n_long][64], -1 = padding
     int32_t* exports;        // [2][count][npad] exportS / exportI scratch of the sparse kernel
     const double* qtop;      // [n][kTopWeights] each row's largest normalised weights, descending (or NULL)
     const double* qtop_seed; // [n_travel][kTopWeights]
@@ -59,6 +68,7 @@ struct EpisodeArgs {
     double* reward_out;      // [count][npad]
     int32_t* flow_s;         // [count][npad] movedS of the last step (WorldToy.scala:106-126)
     int32_t* flow_i;
+    int debug;                  // timing experiments only (0 in production)
     unsigned long long* stats;  // optional [32] search statistics: rows, probes, cold starts, ties, histogram
 };
 

@@ -326,7 +326,8 @@ def _sparse_workload(n, deg, nb, nt, steps, seed):
     return wl
 
 
-@pytest.mark.parametrize("n,deg,nb,nt,steps,eps", [(1300, 6.0, 1, 2, 14, 1.0), (1100, 14.0, 2, 1, 10, 0.4), (2100, 3.0, 1, 1, 8, 1.0)])
+@pytest.mark.parametrize("n,deg,nb,nt,steps,eps", [(1300, 6.0, 1, 2, 14, 1.0), (1100, 14.0, 2, 1, 10, 0.4), (2100, 3.0, 1, 1, 8, 1.0),
+                                                   (1100, 30.0, 1, 2, 8, 1.0)])   # last: many rows beyond 32 stored weights
 def test_grid_sparse_matches_oracle(epi, n, deg, nb, nt, steps, eps):
     """Worlds wider than the dense kernel run on the CSR kernel; eps < 1 makes argmax-Q steps frequent."""
     from epidemicsimulator_amd import synth
