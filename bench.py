@@ -36,6 +36,19 @@ def algorithmic_bytes_per_country_step(n, conn):
     return 8.0 * n + 68.0
 
 
+def measured_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
+    (FETCH_SIZE and WRITE_SIZE are collected in rocprofv3 runs of their own, see profiles/collect.sh and
+    profiles/summarize.py; they cannot be read inside this process).  None when no summary exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_%s.json" % workload)))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return d.get("traffic_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(wl, base, threads, seconds_target=15.0):
     """Oracle timed on a bounded sample: `threads` grid points (one per thread), the first `steps`
     steps of each, sized from a short probe so the leg takes about seconds_target."""
@@ -152,6 +165,7 @@ def main():
     value = total_cs / elapsed
     bpcs = algorithmic_bytes_per_country_step(n, wl["conn"])
     achieved = (k_cs * bpcs / (k_ms * 1e-3)) / 1e9 if k_ms > 0 else 0.0
+    traffic, traffic_src = measured_traffic(wl["name"]) if world == 1 else (None, None)
     out = {
         "metric": "country-steps/sec (calibration grid, whole node)",
         "value": value, "unit": "country-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -163,12 +177,16 @@ def main():
             "parallelism": "grid slabs of %d points per GPU + RCCL all-gather of the fp64 loss surface" % per if world > 1
             else "single GPU", "best_idx": int(best[0]), "best_loss": float(best[1])},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "episode_dense_kernel", "launches": int(k_launches),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": ("%s: per-launch (FETCH_SIZE*2 + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes "
+                                        "of this command" % traffic_src) if traffic_src else None,
+                     "kernel": "episode_csr_kernel" if isinstance(wl["conn"], tuple) else "episode_dense_kernel",
+                     "launches": int(k_launches),
                      "avg_launch_ms": k_ms / max(1, k_launches),
                      "algorithmic_bytes_per_country_step": bpcs,
                      "algorithmic_bytes_per_launch": k_cs * bpcs / max(1, k_launches),
-                     "note": "rank-0 kernel time from HIP events on the launch stream; bytes = (8n+68) per country-step"},
+                     "note": "rank-0 kernel time from HIP events on the launch stream; algorithmic bytes per country-step: "
+                             "8n+68 dense, 12*deg+76 sparse"},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Turns the raw rocprofv3 output of profiles/collect.sh into the committed summaries:
+   python profiles/summarize.py gpurun_out/r1_c3 profiles/round1_c3
+
+Writes <out>.json (read by bench.py for the `traffic` field) and <out>.md, and copies the kernel-stats CSV.
+HBM traffic follows the gfx950 rule for FETCH_SIZE (reported in KiB and exactly half of the bytes of a
+coalesced read; confirmed for this kernel's 8 B/lane pattern with tools/calib_fetch.hip: a 4 GiB read reports
+2,097,155 KiB); WRITE_SIZE (KiB) is taken as is."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def counters(path, kernel_sub):
+    agg = collections.defaultdict(float)
+    launches = collections.Counter()
+    for f in glob.glob(os.path.join(path, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if kernel_sub in r["Kernel_Name"]:
+                agg[r["Counter_Name"]] += float(r["Counter_Value"])
+                launches[r["Counter_Name"]] += 1
+    return dict(agg), dict(launches)
+
+
+def main():
+    src, out = sys.argv[1], sys.argv[2]
+    bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+    kernel_sub = "episode_csr_kernel" if "CSR" in bench["config"]["workload"] else "episode_dense_kernel"
+    stats_csv = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    shutil.copy(stats_csv, out + "_kernel_stats.csv")
+    kstats = [r for r in csv.DictReader(open(stats_csv)) if kernel_sub in r["Name"]][0]
+    c = {}
+    launches = 0
+    for d in ("fetch", "write", "sq", "tcc"):
+        vals, ln = counters(os.path.join(src, d), kernel_sub)
+        c.update(vals)
+        launches = max(launches, max(ln.values()) if ln else 0)
+    fetch_bytes = c.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0
+    write_bytes = c.get("WRITE_SIZE", 0.0) * 1024.0
+    summary = {
+        "workload": bench["config"]["workload"],
+        "bench_line": bench,
+        "rocprof_kernel": kstats["Name"],
+        "rocprof_calls": int(kstats["Calls"]),
+        "rocprof_avg_launch_ms": float(kstats["AverageNs"]) / 1e6,
+        "bench_avg_launch_ms": bench["roofline"]["avg_launch_ms"],
+        "pmc_launches_per_pass": launches,
+        "hbm_read_bytes_per_launch": fetch_bytes / max(1, launches),
+        "hbm_write_bytes_per_launch": write_bytes / max(1, launches),
+        "traffic_bytes_per_launch": (fetch_bytes + write_bytes) / max(1, launches),
+        "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+        "l2_hit_rate": c.get("TCC_HIT_sum", 0.0) / max(1.0, c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 0.0)),
+        "counters_one_sweep": c,
+    }
+    with open(out + ".json", "w") as f:
+        json.dump(summary, f, indent=1)
+        f.write("\n")
+    with open(out + ".md", "w") as f:
+        f.write("# rocprofv3 summary: %s\n\n" % summary["workload"])
+        f.write("| quantity | value |\n|---|---|\n")
+        f.write("| bench value | %.4g %s |\n" % (bench["value"], bench["unit"]))
+        f.write("| roofline.achieved (algorithmic) | %.1f GB/s = %.3f of 8 TB/s |\n" % (bench["roofline"]["achieved"], bench["roofline"]["frac"]))
+        f.write("| kernel | `%s` |\n" % kstats["Name"])
+        f.write("| avg launch, rocprofv3 --kernel-trace --stats | %.2f ms over %s calls |\n" % (summary["rocprof_avg_launch_ms"], kstats["Calls"]))
+        f.write("| avg launch, HIP events in bench.py | %.2f ms |\n" % summary["bench_avg_launch_ms"])
+        f.write("| HBM read per launch (FETCH_SIZE x 1024 x 2) | %.3e B |\n" % summary["hbm_read_bytes_per_launch"])
+        f.write("| HBM write per launch (WRITE_SIZE x 1024) | %.3e B |\n" % summary["hbm_write_bytes_per_launch"])
+        f.write("| algorithmic bytes per launch | %.3e B |\n" % summary["algorithmic_bytes_per_launch"])
+        f.write("| L2 hit rate (TCC_HIT / (HIT+MISS)) | %.3f |\n" % summary["l2_hit_rate"])
+        for k in sorted(c):
+            f.write("| %s (one sweep) | %.4g |\n" % (k, c[k]))
+        if "cpu_baseline" in bench:
+            f.write("| cpu_baseline | %.4g %s on %d threads (%s) |\n" % (bench["cpu_baseline"]["value"], bench["cpu_baseline"]["unit"],
+                                                                        bench["cpu_baseline"]["cores"], bench["cpu_baseline"]["sample"]))
+    print("wrote", out + ".json", out + ".md")
+
+
+if __name__ == "__main__":
+    main()
