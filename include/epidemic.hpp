@@ -1,0 +1,449 @@
+// epidemic.hpp -- C++ host-side mirror of the reference's Scala interface for the metapopulation
+// step and the calibration sweep, over the C ABI of include/epi.h.
+//
+// Same names, argument meaning and error behaviour as the Scala sources under
+// src/main/scala/epidemic/ (cited per item); the arithmetic of the path runs in libepi.so on the
+// GPU.  `require(...)` failures of the reference (IllegalArgumentException) surface here as
+// epidemic::IllegalArgumentException.  Header-only; link with -lepi.
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "epi.h"
+
+namespace epidemic {
+
+struct IllegalArgumentException : std::invalid_argument {
+    using std::invalid_argument::invalid_argument;
+};
+
+inline void check(int32_t status) {
+    if (status == EPI_OK) return;
+    char buf[1024];
+    epi_last_error(buf, sizeof buf);
+    if (status == EPI_ERR_LOCAL_MASS || status == EPI_ERR_WORLD_MASS || status == EPI_ERR_ASSERT_STATE)
+        throw IllegalArgumentException(buf);
+    throw std::runtime_error(std::string("epi status ") + std::to_string(status) + ": " + buf);
+}
+
+// ---- env.scala:6-30 -----------------------------------------------------------------------------
+enum class Action : int { NoneA = 0, Distancing, TravelBan, Lockdown, NormalCare, SurgeCare, TargetedVax, MassVax };
+inline Action fromId(int i) { return static_cast<Action>(i < 0 ? 0 : (i > 7 ? 7 : i)); }  // env.scala:18-20
+
+struct State {  // env.scala:22-30
+    double s = 0, i = 0, r = 0, d = 0, v = 0, hospCap = 0;
+    int t = 0, tMax = 0, seed = 0;
+    double n() const { return s + i + r + d; }
+    double util() const { return i / std::fmax(1.0, hospCap); }
+    std::array<double, 7> features() const {
+        const double N = std::fmax(1.0, n());
+        return {s / N, i / N, r / N, d / N, v / N, util(), static_cast<double>(t) / (tMax > 1 ? tMax : 1)};
+    }
+    epi_state c() const { return epi_state{s, i, r, d, v, hospCap, t, tMax, seed, 0}; }
+    static State from(const epi_state& c) { return State{c.s, c.i, c.r, c.d, c.v, c.hosp_cap, c.t, c.t_max, c.seed}; }
+    bool operator==(const State& o) const {
+        return s == o.s && i == o.i && r == o.r && d == o.d && v == o.v && hospCap == o.hospCap && t == o.t && tMax == o.tMax;
+    }
+};
+
+// ---- config.scala ---------------------------------------------------------------------------------
+struct HyperParams {
+    double gamma = 0.99, lr = 1e-3, epsilonStart = 1.0, epsilonEnd = 0.1;
+    int epsilonDecaySteps = 100000, targetUpdateEvery = 1500, replayCapacity = 50000, batchSize = 128, hidden = 128;
+    double clipQ = 10.0, rewardClip = 5.0, gradClip = 1.0;
+    int logInterval = 500;
+    double emaAlpha = 0.0;
+    bool checkpoint = true;
+    int learnEvery = 8;
+    epi_hyper c() const { return epi_hyper{epsilonStart, epsilonEnd, epsilonDecaySteps, hidden, clipQ, rewardClip, batchSize, learnEvery}; }
+};
+struct TrainConfig {
+    int epochs = 1000, stepsPerEpoch = 500, evalEvery = 10;
+};
+
+// ---- Geo.scala ------------------------------------------------------------------------------------
+namespace Geo {
+struct Country {  // Geo.scala:4-21
+    std::string name;
+    int pop = 0;
+    double lat = 0, lon = 0, hospPer1k = 3.0, betaMul = 1.0, ifrMul = 1.0, noise = 0.05, populationDensity = 100.0,
+           gdpPerCapita = 30000.0, healthcareCapacity = 0.7, mobilityIndex = 0.8, ageDistributionElderly = 0.15,
+           climateFactor = 0.6, connectivityStrength = 0.8, economicResilience = 0.7;
+    epi_profile c() const {
+        return epi_profile{betaMul, ifrMul, noise, populationDensity, gdpPerCapita, healthcareCapacity, ageDistributionElderly,
+                           connectivityStrength, economicResilience};
+    }
+};
+inline Country getProfile(const std::string& name) {  // CountryProfiles.getProfile, Geo.scala:24-68
+    if (name == "USA") return {"USA", 331000000, 39.8, -98.5, 2.9, 1.0, 1.0, 0.05, 36.0, 65000.0, 0.85, 0.9, 0.20, 0.7, 0.95, 0.9};
+    if (name == "Japan") return {"Japan", 125000000, 36.2, 138.2, 13.1, 0.8, 0.9, 0.03, 347.0, 42000.0, 0.95, 0.6, 0.30, 0.5, 0.8, 0.8};
+    if (name == "India") return {"India", 1380000000, 20.6, 78.9, 0.5, 1.3, 1.2, 0.08, 464.0, 2100.0, 0.3, 0.4, 0.07, 0.8, 0.4, 0.3};
+    if (name == "Italy") return {"Italy", 60000000, 41.9, 12.6, 3.2, 1.1, 1.4, 0.04, 206.0, 35000.0, 0.8, 0.7, 0.28, 0.6, 0.85, 0.7};
+    if (name == "Germany") return {"Germany", 83000000, 51.2, 10.5, 8.0, 0.9, 0.8, 0.03, 240.0, 46000.0, 0.9, 0.8, 0.25, 0.4, 0.9, 0.85};
+    if (name == "China") return {"China", 1400000000, 35.9, 104.2, 4.3, 1.0, 1.0, 0.06, 153.0, 10500.0, 0.6, 0.5, 0.18, 0.7, 0.7, 0.6};
+    Country c;
+    c.name = name;
+    c.pop = 50000000;
+    return c;
+}
+inline double haversineKm(double lat1, double lon1, double lat2, double lon2) {  // Geo.scala:72-79
+    const double R = 6371.0, rad = 3.14159265358979323846 / 180.0;
+    const double dLat = (lat2 - lat1) * rad, dLon = (lon2 - lon1) * rad;
+    const double a = std::pow(std::sin(dLat / 2), 2) + std::cos(lat1 * rad) * std::cos(lat2 * rad) * std::pow(std::sin(dLon / 2), 2);
+    return R * (2 * std::atan2(std::sqrt(a), std::sqrt(1 - a)));
+}
+}  // namespace Geo
+
+using Matrix = std::vector<std::vector<double>>;
+
+inline std::vector<double> flatten(const Matrix& W) {
+    std::vector<double> f;
+    for (const auto& r : W) f.insert(f.end(), r.begin(), r.end());
+    return f;
+}
+
+// ---- ToyConn.scala --------------------------------------------------------------------------------
+namespace ToyConn {
+inline const std::vector<Geo::Country>& C() {  // ToyConn.scala:7-14
+    static const std::vector<Geo::Country> c = {
+        {"USA", 330000000, 38.0, -97.0, 2.9, 1.00, 1.00, 0.05},    {"Japan", 125000000, 36.0, 138.0, 7.8, 0.92, 0.90, 0.04},
+        {"Italy", 60000000, 42.5, 12.5, 3.2, 0.98, 1.05, 0.05},    {"India", 1420000000, 22.0, 79.0, 0.7, 1.05, 0.95, 0.06},
+        {"Germany", 83000000, 51.0, 10.0, 8.0, 0.96, 0.95, 0.04}, {"China", 1410000000, 35.0, 103.0, 4.3, 1.03, 1.00, 0.05}};
+    return c;
+}
+inline double flightMul(const std::string& a, const std::string& b) {  // ToyConn.scala:16-20
+    static const std::map<std::pair<std::string, std::string>, double> m = {
+        {{"China", "India"}, 1.8}, {{"India", "China"}, 1.2}, {{"USA", "Japan"}, 1.6}, {{"Japan", "USA"}, 1.6},
+        {{"Germany", "Italy"}, 1.3}, {{"Italy", "Germany"}, 1.2}};
+    auto it = m.find({a, b});
+    return it == m.end() ? 1.0 : it->second;
+}
+// ToyConn.scala:22-47.  Uses the host libm; the JVM's Math.pow/sin/cos may differ in the last ulp, so the
+// matrix is an engine input rather than something the engine reproduces.
+inline Matrix gravityMatrix(const std::vector<Geo::Country>& cs, double a = 0.2, double b = 1.0, double g = 1.2, double k = 1e-6,
+                            double capRow = 0.12) {
+    const size_t n = cs.size();
+    Matrix W(n, std::vector<double>(n, 0.0));
+    for (size_t i = 0; i < n; ++i) {
+        double rowSum = 0.0;
+        for (size_t j = 0; j < n; ++j)
+            if (i != j) {
+                const double d = std::fmax(300.0, Geo::haversineKm(cs[i].lat, cs[i].lon, cs[j].lat, cs[j].lon));
+                const double w = k * std::pow((double)cs[i].pop, a) * std::pow((double)cs[j].pop, b) * flightMul(cs[i].name, cs[j].name) / std::pow(d, g);
+                W[i][j] = w;
+                rowSum += w;
+            }
+        if (rowSum > 0) {
+            const double scale = std::fmin(1.0, capRow / rowSum);
+            for (size_t j = 0; j < n; ++j)
+                if (i != j) W[i][j] *= scale;
+        }
+        W[i][i] = 0.0;
+    }
+    return W;
+}
+inline const Matrix& W() {
+    static const Matrix w = gravityMatrix(C());
+    return w;
+}
+inline Matrix scaleEdge(const Matrix& W, int src, int dst, double factor) {  // ToyConn.scala:51-55
+    Matrix A = W;
+    A[src][dst] *= factor;
+    return A;
+}
+inline Matrix scaleRow(const Matrix& W, int row, double factor) {  // ToyConn.scala:58-70
+    const int n = (int)W.size();
+    std::vector<double> in = flatten(W), out(in.size());
+    check(epi_scale_row(in.data(), n, row, factor, out.data()));
+    Matrix A(n, std::vector<double>(n));
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) A[i][j] = out[(size_t)i * n + j];
+    return A;
+}
+}  // namespace ToyConn
+
+// ---- Validation.scala -----------------------------------------------------------------------------
+namespace Validation {
+struct Invariants {
+    int pop, tMax;
+};
+struct Metrics {
+    int arrival;
+    double peakI, finalI;
+};
+inline void assertState(const State& s, const Invariants& inv) {  // Validation.scala:6-11
+    if (!(s.s >= 0 && s.i >= 0 && s.r >= 0 && s.d >= 0 && s.v >= 0)) throw IllegalArgumentException("requirement failed: neg compartment");
+    const double total = s.s + s.i + s.r + s.d + s.v;
+    if ((int)std::floor(total + 0.5) != inv.pop) throw IllegalArgumentException("requirement failed: mass not conserved");
+    if (!(s.t >= 0 && s.t <= inv.tMax)) throw IllegalArgumentException("requirement failed: t out of bounds");
+}
+inline int arrivalTime(const std::vector<double>& iSeries, double thresh = 10.0) {  // :15-19
+    for (size_t k = 0; k < iSeries.size(); ++k)
+        if (iSeries[k] >= thresh) return (int)k;
+    return (int)iSeries.size();
+}
+inline double peakI(const std::vector<double>& iSeries) {  // :21-22
+    double m = 0.0;
+    for (size_t k = 0; k < iSeries.size(); ++k) m = (k == 0 || iSeries[k] > m) ? iSeries[k] : m;
+    return m;
+}
+}  // namespace Validation
+
+// ---- env.scala:32-255 -----------------------------------------------------------------------------
+class EpidemicEnv {
+public:
+    EpidemicEnv(double baseBeta = 0.35, double baseGamma = 0.12, double baseIFR = 0.008, double noise = 0.05, double rewardClip = 5.0,
+                double riskFactor = 0.0, std::string countryName = "Unknown", int seed = 42)
+        : p_{baseBeta, baseGamma, baseIFR, noise, rewardClip, riskFactor}, name_(std::move(countryName)), seed_(seed),
+          profile_(Geo::getProfile(name_)) {}
+
+    State reset(const State& s0) const { return s0; }
+    struct EnvParams {
+        double beta, gamma, ifr, noise;
+    };
+    EnvParams params() const { return {p_.base_beta, p_.base_gamma, p_.base_ifr, p_.noise}; }
+    const epi_env_params& raw() const { return p_; }
+    const Geo::Country& countryProfile() const { return profile_; }
+    int seed() const { return seed_; }
+
+    // env.scala:58-140; the Gaussian draw comes from this env's own Random(seed) stream (env.scala:42,91)
+    std::tuple<State, double, bool> step(const State& st, Action act) {
+        if (pos_ >= gauss_.size()) {
+            gauss_.resize(gauss_.empty() ? 64 : gauss_.size() * 2);
+            check(epi_java_gaussians(seed_, (int32_t)gauss_.size(), gauss_.data()));
+        }
+        const double z = gauss_[pos_++];
+        const epi_state in = st.c();
+        const epi_profile pr = profile_.c();
+        const int32_t a = static_cast<int>(act);
+        epi_state out;
+        double reward = 0;
+        uint8_t done = 0;
+        check(epi_env_step_batch(&p_, &pr, &in, &a, &z, &out, &reward, &done, 1));
+        return {State::from(out), reward, done != 0};
+    }
+
+    static std::vector<int> allocateInt(int total, const std::vector<double>& weights) {  // env.scala:241-254
+        std::vector<int32_t> out(weights.size(), 0);
+        check(epi_alloc_int(total, weights.data(), (int32_t)weights.size(), out.data()));
+        return std::vector<int>(out.begin(), out.end());
+    }
+
+private:
+    epi_env_params p_;
+    std::string name_;
+    int seed_;
+    Geo::Country profile_;
+    std::vector<double> gauss_;
+    size_t pos_ = 0;
+};
+
+// ---- WorldToy.scala -------------------------------------------------------------------------------
+class WorldToy {
+public:
+    struct Node {
+        int idx;
+        std::string name;
+        int pop;
+        std::shared_ptr<EpidemicEnv> env;
+        HyperParams hyperParams;
+        State s;
+        int lastA = 0;
+    };
+    using Step = std::vector<std::tuple<std::string, State, double>>;
+
+    WorldToy(const HyperParams& hp, const State& base, int seedIdx = 0, const Matrix& conn = ToyConn::W(),
+             std::function<std::shared_ptr<EpidemicEnv>()> makeEnv = [] { return std::make_shared<EpidemicEnv>(); },
+             std::function<std::shared_ptr<EpidemicEnv>(const std::string&, int)> makeEnvFor = nullptr, bool validate = false,
+             const std::vector<Geo::Country>& countries = ToyConn::C())
+        : hp_(hp), base_(base) {
+        const int n = (int)countries.size();
+        std::vector<int32_t> pops, seeds;
+        std::vector<epi_env_params> envs;
+        std::vector<epi_profile> profs;
+        for (int i = 0; i < n; ++i) {
+            auto env = makeEnvFor ? makeEnvFor(countries[i].name, countries[i].pop) : makeEnv();
+            pops.push_back(countries[i].pop);
+            seeds.push_back(env->seed());
+            envs.push_back(env->raw());
+            profs.push_back(env->countryProfile().c());
+            nodes.push_back(Node{i, countries[i].name, countries[i].pop, env, hp, State{}});
+        }
+        const std::vector<double> flat = flatten(conn);
+        epi_world_desc d{};
+        d.n = n; d.batch = 1; d.pop = pops.data(); d.conn = flat.data();
+        d.seed_idx = seedIdx; d.validate = validate ? 1 : 0; d.base = base.c();
+        d.env = envs.data(); d.prof = profs.data(); d.env_seeds = seeds.data(); d.hp = hp.c(); d.device = 0;
+        h_ = epi_world_create(&d);
+        if (!h_) {
+            char buf[1024];
+            epi_last_error(buf, sizeof buf);
+            if (std::string(buf).find("requirement failed") != std::string::npos) throw IllegalArgumentException(buf);
+            throw std::runtime_error(buf);
+        }
+        syncNodes();
+    }
+    ~WorldToy() { epi_world_destroy(h_); }
+    WorldToy(const WorldToy&) = delete;
+    WorldToy& operator=(const WorldToy&) = delete;
+
+    std::vector<Node> nodes;
+
+    std::vector<State> snapshotStates() {  // WorldToy.scala:75
+        std::vector<epi_state> raw(nodes.size());
+        check(epi_world_get_states(h_, raw.data()));
+        std::vector<State> out;
+        for (auto& r : raw) out.push_back(State::from(r));
+        return out;
+    }
+    void restoreStates(const std::vector<State>& ss) {  // :76
+        std::vector<epi_state> raw;
+        for (auto& s : ss) raw.push_back(s.c());
+        check(epi_world_set_states(h_, raw.data()));
+        syncNodes();
+    }
+    void resetToInitial() {  // :77
+        check(epi_world_reset(h_));
+        syncNodes();
+    }
+
+    // WorldToy.stepOne (:83-170) with never-trained agents: epsilon-greedy draws follow the JVM streams;
+    // the DDQN update itself stays with the trainer.
+    Step stepOne(int tMax) {
+        const int n = (int)nodes.size();
+        if (streams_.empty()) streams_.resize(n);
+        std::vector<int32_t> acts(n);
+        bool needGreedy = false;
+        for (int c = 0; c < n; ++c) {
+            auto& st = streams_[c];
+            if (st.pos >= st.buf.size()) {
+                st.buf.resize(st.buf.empty() ? 256 : st.buf.size() * 2);
+                const epi_hyper h = hp_.c();
+                check(epi_agent_actions(&h, (int32_t)st.buf.size(), st.buf.data()));
+            }
+            acts[c] = st.buf[st.pos++];
+            needGreedy = needGreedy || acts[c] < 0;
+        }
+        if (needGreedy) {
+            ensureMlp();
+            std::vector<epi_state> raw;
+            for (auto& nd : nodes) raw.push_back(nd.s.c());
+            std::vector<int32_t> g(n);
+            check(epi_mlp_greedy_batch(raw.data(), n, hp_.hidden, W1_.data(), nullptr, W2_.data(), nullptr, W3_.data(), nullptr,
+                                       hp_.clipQ, nullptr, g.data()));
+            for (int c = 0; c < n; ++c)
+                if (acts[c] < 0) acts[c] = g[c];
+        }
+        std::vector<epi_state> out(n);
+        std::vector<double> rew(n);
+        check(epi_world_step(h_, acts.data(), nullptr, tMax, out.data(), rew.data()));
+        return collect(out, rew, acts);
+    }
+
+    Step stepOneGreedy(int tMax) {  // :172-235
+        ensureMlp();
+        const int n = (int)nodes.size();
+        std::vector<epi_state> out(n);
+        std::vector<double> rew(n);
+        std::vector<int32_t> acts(n);
+        check(epi_world_step_greedy(h_, nullptr, tMax, out.data(), rew.data(), acts.data()));
+        return collect(out, rew, acts);
+    }
+
+    std::pair<std::vector<int>, std::vector<int>> lastFlows() {
+        std::vector<int32_t> s(nodes.size()), i(nodes.size());
+        check(epi_world_last_flows(h_, s.data(), i.data()));
+        return {std::vector<int>(s.begin(), s.end()), std::vector<int>(i.begin(), i.end())};
+    }
+
+private:
+    struct Stream {
+        std::vector<int32_t> buf;
+        size_t pos = 0;
+    };
+    void syncNodes() {
+        auto ss = snapshotStates();
+        for (size_t c = 0; c < nodes.size(); ++c) nodes[c].s = ss[c];
+    }
+    void ensureMlp() {
+        if (!W1_.empty()) return;
+        W1_.resize((size_t)hp_.hidden * 7);
+        W2_.resize((size_t)hp_.hidden * hp_.hidden);
+        W3_.resize((size_t)8 * hp_.hidden);
+        check(epi_mlp_init(7, hp_.hidden, 8, W1_.data(), W2_.data(), W3_.data()));
+        check(epi_world_set_mlp(h_, hp_.hidden, W1_.data(), nullptr, W2_.data(), nullptr, W3_.data(), nullptr, hp_.clipQ));
+    }
+    Step collect(const std::vector<epi_state>& out, const std::vector<double>& rew, const std::vector<int32_t>& acts) {
+        Step res;
+        for (size_t c = 0; c < nodes.size(); ++c) {
+            nodes[c].s = State::from(out[c]);
+            nodes[c].lastA = acts[c];
+            res.emplace_back(nodes[c].name, nodes[c].s, rew[c]);
+        }
+        return res;
+    }
+    HyperParams hp_;
+    State base_;
+    epi_world* h_ = nullptr;
+    std::vector<Stream> streams_;
+    std::vector<double> W1_, W2_, W3_;
+};
+
+// ---- Calibrate.scala ------------------------------------------------------------------------------
+namespace Calibrate {
+struct Targets {  // Calibrate.scala:8-12
+    std::map<std::string, double> tArrive, peakI;
+    double threshI = 10.0;
+};
+using Row = std::tuple<double, double, double>;
+using Surface = std::pair<std::vector<Row>, std::pair<double, std::pair<double, double>>>;
+
+// Calibrate.gridSurface (:84-116): rows (beta, ts, loss) in loop order and (bestLoss, (beta, ts)).
+inline Surface gridSurface(const HyperParams& hp, const TrainConfig& cfg, const State& base, int seedIdx, const Targets& targets,
+                           const std::vector<double>& betaGrid, const std::vector<double>& travelScales, bool /*validate*/ = true,
+                           bool heterogeneous = true, const std::vector<Geo::Country>& countries = ToyConn::C(),
+                           const Matrix& conn = ToyConn::W()) {
+    const int n = (int)countries.size();
+    std::pair<double, double> bestPair{betaGrid.empty() ? 0.25 : betaGrid[0], travelScales.empty() ? 1.0 : travelScales[0]};
+    if (betaGrid.empty() || travelScales.empty()) return {{}, {1.7976931348623157e308, bestPair}};
+    std::vector<int32_t> pops;
+    std::vector<epi_profile> profs;
+    std::vector<double> ta(n, 0.0), tp(n, 0.0);
+    std::vector<uint8_t> ha(n, 0), hk(n, 0);
+    for (int c = 0; c < n; ++c) {
+        pops.push_back(countries[c].pop);
+        profs.push_back(Geo::getProfile(countries[c].name).c());
+        auto a = targets.tArrive.find(countries[c].name);
+        if (a != targets.tArrive.end()) { ta[c] = a->second; ha[c] = 1; }
+        auto p = targets.peakI.find(countries[c].name);
+        if (p != targets.peakI.end()) { tp[c] = p->second; hk[c] = 1; }
+    }
+    const std::vector<double> flat = flatten(conn);
+    epi_grid_desc d{};
+    d.n = n; d.pop = pops.data(); d.conn = flat.data(); d.seed_idx = seedIdx; d.heterogeneous = heterogeneous ? 1 : 0;
+    d.base = base.c(); d.prof = profs.data(); d.hp = hp.c(); d.steps = cfg.stepsPerEpoch;
+    d.n_beta = (int)betaGrid.size(); d.betas = betaGrid.data(); d.n_travel = (int)travelScales.size(); d.travel = travelScales.data();
+    d.t_arrive = ta.data(); d.has_arrive = ha.data(); d.t_peak = tp.data(); d.has_peak = hk.data(); d.device = 0;
+    std::vector<double> loss(betaGrid.size() * travelScales.size());
+    int32_t bestIdx = 0;
+    double bestLoss = 0;
+    check(epi_calibrate_grid(&d, loss.data(), nullptr, nullptr, &bestIdx, &bestLoss));
+    std::vector<Row> rows;
+    for (size_t b = 0; b < betaGrid.size(); ++b)
+        for (size_t k = 0; k < travelScales.size(); ++k) rows.emplace_back(betaGrid[b], travelScales[k], loss[b * travelScales.size() + k]);
+    if (bestLoss < 1.7976931348623157e308) bestPair = {std::get<0>(rows[bestIdx]), std::get<1>(rows[bestIdx])};
+    return {rows, {bestLoss, bestPair}};
+}
+}  // namespace Calibrate
+
+}  // namespace epidemic

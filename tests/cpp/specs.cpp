@@ -1,0 +1,167 @@
+// The reference's own ScalaTest specs for this path (src/test/scala/epidemic/*.scala), restated against
+// the C++ mirror include/epidemic.hpp.  Needs a GPU: every call below runs in libepi.so.
+// Built by __graft_entry__.build(); run by tests/test_gpu_cpp_mirror.py.  Exit code 0 = all specs pass.
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+
+#include "epidemic.hpp"
+
+using namespace epidemic;
+
+static int failures = 0;
+#define EXPECT(cond)                                                        \
+    do {                                                                    \
+        if (!(cond)) {                                                      \
+            std::printf("  FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+            ++failures;                                                     \
+        }                                                                   \
+    } while (0)
+
+// ValidationSpec.scala:7-22
+static void validationSpec() {
+    State s{9, 1, 0, 0, 0, 10, 0, 10, 1};
+    Validation::assertState(s, Validation::Invariants{10, 10});
+    EXPECT(Validation::arrivalTime({1.0, 2.0, 3.0, 4.0, 5.0}, 10.0) == 5);
+    EXPECT(Validation::peakI({}) == 0.0);
+    EXPECT(std::fabs(Validation::peakI({0.1, 0.5, 0.3}) - 0.5) <= 1e-12);
+    bool threw = false;
+    try {
+        Validation::assertState(State{9, 2, 0, 0, 0, 10, 0, 10, 1}, Validation::Invariants{10, 10});
+    } catch (const IllegalArgumentException&) {
+        threw = true;
+    }
+    EXPECT(threw);
+}
+
+// MobilitySpec.scala:7-14 and :24-63
+static void mobilitySpec() {
+    const Matrix& W = ToyConn::W();
+    const int n = (int)W.size();
+    for (int i = 0; i < n; ++i) {
+        EXPECT(W[i][i] == 0.0);
+        EXPECT(std::accumulate(W[i].begin(), W[i].end(), 0.0) <= 0.12 + 1e-12);
+    }
+    const double S[6] = {1000000, 120000, 1000000, 80000, 60000, 300000};
+    const double I[6] = {1000, 200, 900, 100, 80, 400};
+    std::vector<long long> movedS(n, 0), movedI(n, 0);
+    for (int i = 0; i < n; ++i) {
+        std::vector<double> wRow(n);
+        double sumW = 0.0;
+        for (int j = 0; j < n; ++j) {
+            wRow[j] = (j == i) ? 0.0 : W[i][j];
+            sumW = (j == 0) ? wRow[0] : sumW + wRow[j];
+        }
+        sumW = std::fmax(0.0, sumW);
+        const int Si = (int)S[i], Ii = (int)I[i];
+        const int exportS = (int)std::min<long long>(Si, (long long)std::floor(Si * sumW + 1e-9));
+        const int exportI = (int)std::min<long long>(Ii, (long long)std::floor(Ii * sumW + 1e-9));
+        const std::vector<int> allocS = EpidemicEnv::allocateInt(exportS, wRow);
+        const std::vector<int> allocI = EpidemicEnv::allocateInt(exportI, wRow);
+        for (int j = 0; j < n; ++j)
+            if (j != i) { movedS[j] += allocS[j]; movedI[j] += allocI[j]; }
+        movedS[i] -= exportS;
+        movedI[i] -= exportI;
+    }
+    long long net = 0;
+    for (int j = 0; j < n; ++j) net += movedS[j] + movedI[j];
+    EXPECT(net == 0);
+    // allocateInt known answers (env.scala:241-254)
+    EXPECT((EpidemicEnv::allocateInt(10, {.5, .3, .2}) == std::vector<int>{5, 3, 2}));
+    EXPECT((EpidemicEnv::allocateInt(10, {1, 1, 1}) == std::vector<int>{4, 3, 3}));
+    EXPECT((EpidemicEnv::allocateInt(7, {0, 2, 1, 1}) == std::vector<int>{0, 3, 2, 2}));
+    EXPECT((EpidemicEnv::allocateInt(1, {.25, .25, .25, .25}) == std::vector<int>{1, 0, 0, 0}));
+    EXPECT((EpidemicEnv::allocateInt(5, {0, 0, 0}) == std::vector<int>{0, 0, 0}));
+}
+
+// CalibrationSpec.scala:6-16
+static void calibrationSpec() {
+    HyperParams hp;
+    TrainConfig cfg;
+    cfg.epochs = 1;
+    cfg.stepsPerEpoch = 60;
+    State base{1000000, 0, 0, 0, 0, 10000, 0, 60, 3};
+    Calibrate::Targets targets;
+    auto res = Calibrate::gridSurface(hp, cfg, base, 0, targets, {0.24, 0.26}, {0.8, 1.0}, false, false);
+    EXPECT(!res.first.empty());
+    EXPECT(std::isfinite(res.second.first));
+    EXPECT(res.second.first == 0.0);  // empty targets: every difference is 0
+    EXPECT(res.second.second.first == 0.24 && res.second.second.second == 0.8);
+}
+
+// EvalDeterminismSpec.scala:7-45
+static void evalDeterminismSpec() {
+    auto makeWorld = [] {
+        HyperParams hp0;
+        hp0.learnEvery = 2147483647;
+        State base{0, 0, 0, 0, 0, 10000, 0, 120, 42};
+        return std::make_unique<WorldToy>(
+            hp0, base, 0, ToyConn::W(), [hp0] { return std::make_shared<EpidemicEnv>(0.26, 0.12, 0.008, 0.02, hp0.rewardClip); }, nullptr,
+            false);
+    };
+    auto runEvalSeries = [](WorldToy& w, int steps) {
+        std::vector<double> out;
+        for (int k = 0; k < steps; ++k) {
+            auto batch = w.stepOneGreedy(steps);
+            for (auto& row : batch)
+                if (std::get<0>(row) == "USA") out.push_back(std::get<1>(row).i);
+        }
+        return out;
+    };
+    auto w1 = makeWorld(), w2 = makeWorld();
+    const auto a = runEvalSeries(*w1, 100), b = runEvalSeries(*w2, 100);
+    EXPECT(a.size() == 100 && a == b);
+    // snapshot / reset / restore round trip (WorldToy.scala:75-77, MutliTrainer.scala:130-160)
+    const auto snap = w1->snapshotStates();
+    w1->resetToInitial();
+    EXPECT(w1->nodes[0].s.i == 330000.0 && w1->nodes[1].s.i == 0.0);
+    w1->restoreStates(snap);
+    EXPECT(w1->snapshotStates() == snap);
+    // stepOne conserves world mass (validate = true would throw otherwise)
+    HyperParams hp;
+    WorldToy w3(hp, State{0, 0, 0, 0, 0, 10000, 0, 120, 42}, 0, ToyConn::W(), [] { return std::make_shared<EpidemicEnv>(); }, nullptr, true);
+    double before = 0, after = 0;
+    for (auto& nd : w3.nodes) before += nd.s.s + nd.s.i + nd.s.r + nd.s.d + nd.s.v;
+    for (int k = 0; k < 30; ++k) w3.stepOne(120);
+    for (auto& nd : w3.nodes) after += nd.s.s + nd.s.i + nd.s.r + nd.s.d + nd.s.v;
+    EXPECT(before == after);
+}
+
+// HeterogeneitySpec.scala:18-29
+static void heterogeneitySpec() {
+    auto makeEnvFor = [](const Geo::Country& c) { return EpidemicEnv(0.26 * c.betaMul, 0.12, 0.008 * c.ifrMul, c.noise, 5.0); };
+    Geo::Country cn, jp;
+    for (auto& c : ToyConn::C()) {
+        if (c.name == "China") cn = c;
+        if (c.name == "Japan") jp = c;
+    }
+    State s0{1000000, 1000, 0, 0, 0, 10000, 0, 10, 1};
+    auto envCn = makeEnvFor(cn), envJp = makeEnvFor(jp);
+    const State sCn1 = std::get<0>(envCn.step(s0, fromId(0)));
+    const State sJp1 = std::get<0>(envJp.step(s0, fromId(0)));
+    EXPECT(sCn1.i != sJp1.i);
+    EXPECT(sCn1.s + sCn1.i + sCn1.r + sCn1.d + sCn1.v == 1001000.0);
+}
+
+int main() {
+    if (epi_device_count() < 1) {
+        std::printf("no HIP device: the specs need the GPU engine\n");
+        return 2;
+    }
+    struct {
+        const char* name;
+        void (*fn)();
+    } specs[] = {{"ValidationSpec", validationSpec}, {"MobilitySpec", mobilitySpec}, {"CalibrationSpec", calibrationSpec},
+                 {"EvalDeterminismSpec", evalDeterminismSpec}, {"HeterogeneitySpec", heterogeneitySpec}};
+    for (auto& s : specs) {
+        const int before = failures;
+        try {
+            s.fn();
+        } catch (const std::exception& e) {
+            std::printf("  EXCEPTION in %s: %s\n", s.name, e.what());
+            ++failures;
+        }
+        std::printf("%s %s\n", failures == before ? "PASS" : "FAIL", s.name);
+    }
+    return failures == 0 ? 0 : 1;
+}
