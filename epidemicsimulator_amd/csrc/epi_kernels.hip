@@ -231,7 +231,7 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
 // fractions up to a rounding error far below 1, and every fraction is below 1), so the units go
 // to stored entries only; the kernel checks this and reports EPI_ERR_UNSUPPORTED otherwise.
 // ---------------------------------------------------------------------------------------------
-constexpr int kCsrThreads = 512;  // 8 waves: room for a whole row of keys per lane without spilling
+constexpr int kCsrThreads = 768;  // 8 waves: room for a whole row of keys per lane without spilling
 
 template <int DMAX>
 __device__ __forceinline__ void lane_apportion(int32_t E, int D, const double* __restrict__ qp, int qstride,
