@@ -109,8 +109,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # EPI_BENCH_FORCE_DIST=1 runs the RCCL exchange even with a single rank (rehearsal on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("EPI_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import epidemicsimulator_amd as E
     from epidemicsimulator_amd import synth
@@ -132,11 +136,11 @@ def main():
     def one_step():
         if cnt > 0:
             eng.enqueue(g0, cnt, loss_local.data_ptr(), stream)
-        host = gather_surface(loss_local, G, world)  # 8*G bytes back to the host
+        host = gather_surface(loss_local, G, world, force=use_dist)  # 8*G bytes back to the host
         return E.grid_argmin(host)                   # Calibrate.scala:112's strict '<' scan
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -157,7 +161,7 @@ def main():
     eng.set_timing(False)
 
     tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
 
@@ -193,7 +197,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl, base, args.cpu_threads)
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -18,12 +18,12 @@ def slab_bounds(grid_points: int, world: int, rank: int) -> Tuple[int, int, int]
     return g0, cnt, per
 
 
-def gather_surface(loss_local, grid_points: int, world: int):
+def gather_surface(loss_local, grid_points: int, world: int, force: bool = False):
     """All-gathers the padded per-rank slabs (torch tensors of equal length) and returns the surface
     as a host numpy array of length grid_points."""
     import torch
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or force:
         full = torch.empty(loss_local.numel() * world, dtype=loss_local.dtype, device=loss_local.device)
         dist.all_gather_into_tensor(full, loss_local)
     else:
