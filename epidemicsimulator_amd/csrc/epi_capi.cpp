@@ -924,7 +924,6 @@ EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, doub
     ea.actions = g->actions.as<int8_t>(); ea.act_t0 = 0;
     ea.noise = g->noise.as<double>(); ea.noise_t0 = 0;
     ea.st = ia.st; ea.cap = ia.cap; ea.tcur = ia.tcur; ea.arrival = ia.arrival; ea.peak = ia.peak; ea.err = ia.err;
-    if (getenv("EPI_DEBUG")) { ea.debug = atoi(getenv("EPI_DEBUG")); ea.validate = 0; }
     if (getenv("EPI_STATS")) {
         if (!g->stats.p) {
             HIP_TRY(g->stats.ensure(64 * sizeof(unsigned long long)));

@@ -418,7 +418,6 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                     qstride = 1;
                 }
                 const int32_t* __restrict__ cp = a.col + off;
-                if (a.debug & 1) continue;
                 if (__any(ES > 0)) lane_apportion<DMAX>(ES, D, qp, qstride, cp, row, sh_movS, sh_err, t);
                 if (__any(EI > 0)) lane_apportion<DMAX>(EI, D, qp, qstride, cp, row, sh_movI, sh_err, t);
             }

@@ -68,7 +68,6 @@ struct EpisodeArgs {
     double* reward_out;      // [count][npad]
     int32_t* flow_s;         // [count][npad] movedS of the last step (WorldToy.scala:106-126)
     int32_t* flow_i;
-    int debug;                  // timing experiments only (0 in production)
     unsigned long long* stats;  // optional [32] search statistics: rows, probes, cold starts, ties, histogram
 };
 
