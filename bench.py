@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Calibration-sweep benchmark: country-steps/s over the whole beta x travel grid.
 
-  python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c1]
+  python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c1|c4|c5]
 
 One "step" is one pass of the hot path over the whole grid of the workload: every (beta, travel)
 point is one episode of T world steps over n countries, so a step processes G*n*T country-steps.
@@ -89,6 +89,95 @@ def cpu_baseline(wl, base, threads, seconds_target=15.0):
                       % (threads, steps, wl["steps"], wall, probe[0][0] / probe[0][1])}
 
 
+def run_c5(args, rank, local_rank, world, use_dist):
+    """Batched DDQN rollout leg: 4,096 instances of the calibrated toy world (best beta of the toy grid,
+    heterogeneous env parameters as Calibrate.scala:34-51), one epi_world_step per iteration with caller-supplied
+    actions int32[B][n]; the states and rewards of every instance come back to the host each step, as the
+    trainer consumes them.  More GPUs are independent replicas (weak scaling), no collective on the data path."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import epidemicsimulator_amd as E
+    from epidemicsimulator_amd import synth
+
+    B, beta = 4096, 0.26
+    countries = list(E.ToyConn.C)
+    n = len(countries)
+
+    def make_env_for(name, pop):  # Calibrate.scala:34-51
+        p = E.Geo.CountryProfiles.get_profile(name)
+        fb = beta * (1.0 + (p.population_density / 1000.0) * 0.5) * (3.0 - p.healthcare_capacity * 2.0)
+        fi = 0.008 * (1.0 + p.age_distribution_elderly * 2.0)
+        fn = 0.05 * (1.0 + (1.0 - p.economic_resilience))
+        return E.EpidemicEnv(fb, 0.12, fi, fn, 5.0, 0.0, name, [c.name for c in countries].index(name) + 42)
+
+    T = 300
+    base = synth.base_state(T)
+    w = E.WorldToy(E.HyperParams(), base, 0, E.ToyConn.W, make_env_for=make_env_for, validate=True, batch=B,
+                   device=local_rank)
+    rng = np.random.Generator(np.random.PCG64(20251226 + rank))
+    acts = rng.integers(0, 8, size=(64, B, n), dtype=np.int32)  # a ring of pre-drawn action batches
+    states = np.empty((B, n), dtype=E.WorldToy.STATE_DTYPE)
+    rewards = np.empty((B, n))
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    k = 0
+    for _ in range(args.warmup):
+        w.step_arrays(acts[k % 64], None, T, states, rewards); k += 1
+    fence()
+    w.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if k % T == 0:
+            w.reset_to_initial()  # episodes of T steps, as the trainer's epochs
+        w.step_arrays(acts[k % 64], None, T, states, rewards); k += 1
+    fence()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_launches, k_cs = w.kernel_time()
+    w.set_timing(False)
+    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if use_dist:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    bpcs = 8.0 * n + 68.0
+    achieved = (k_cs * bpcs / (k_ms * 1e-3)) / 1e9 if k_ms > 0 else 0.0
+    traffic, traffic_src = measured_traffic("c5") if world == 1 else (None, None)
+    out = {
+        "metric": "country-steps/sec (batched world step, whole node)",
+        "value": float(world) * B * n * args.steps / elapsed, "unit": "country-steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(1, args.steps) * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "c5: %d instances of the %d-country toy world, one world step per iteration, actions in, "
+                               "states and rewards out over PCIe every step" % (B, n),
+                   "instances_per_gpu": B, "country_steps_per_step": world * B * n,
+                   "parallelism": "independent replicas" if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": traffic_src, "kernel": "episode_dense_kernel",
+                     "launches": int(k_launches), "avg_launch_ms": k_ms / max(1, k_launches),
+                     "algorithmic_bytes_per_country_step": bpcs,
+                     "algorithmic_bytes_per_launch": B * n * bpcs,
+                     "note": "one-step launches of 4,096 six-country worlds: launch- and transfer-bound, "
+                             "the kernel itself takes avg_launch_ms of ms_per_step"},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            c1 = synth.workload("c1")
+            cb = cpu_baseline(c1, synth.base_state(c1["steps"]), args.cpu_threads)
+            cb["sample"] = "toy-world rollouts of the oracle (same 6-country world and arithmetic, actions from the " \
+                           "agent stream): " + cb["sample"]
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    w.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,6 +204,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    if args.workload.lower() == "c5":
+        return run_c5(args, rank, local_rank, world, use_dist)
 
     import epidemicsimulator_amd as E
     from epidemicsimulator_amd import synth

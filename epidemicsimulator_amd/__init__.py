@@ -469,9 +469,10 @@ class WorldToy:
         self._sync_nodes()
 
     def _sync_nodes(self):
-        st = self._get_states()[0]
-        for node, s in zip(self.nodes, st):
-            node.s = s
+        arr = (_capi.CState * (self.batch * self.n))()
+        check(lib().epi_world_get_states(self._h, arr))
+        for c, node in enumerate(self.nodes):
+            node.s = State._from_c(arr[c])
 
     def last_flows(self):
         ms = np.zeros((self.batch, self.n), dtype=np.int32); mi = np.zeros((self.batch, self.n), dtype=np.int32)
@@ -491,6 +492,36 @@ class WorldToy:
         for node, s, act in zip(self.nodes, states[0], a[0]):
             node.s, node.last_a = s, int(act)
         return states, r
+
+    # numpy image of one State record as the C ABI lays it out (epi_state, 64 bytes)
+    STATE_DTYPE = np.dtype([("s", "f8"), ("i", "f8"), ("r", "f8"), ("d", "f8"), ("v", "f8"), ("hosp_cap", "f8"),
+                            ("t", "i4"), ("t_max", "i4"), ("seed", "i4"), ("pad_", "i4")])
+
+    def step_arrays(self, actions, gauss=None, t_max: Optional[int] = None, out_states=None, out_rewards=None):
+        """step_actions without per-State Python objects, for batched rollouts: actions int32 [batch][n],
+        gauss float64 [batch][n] or None; fills and returns (out_states: STATE_DTYPE [batch][n],
+        out_rewards: float64 [batch][n]).  `nodes` is not refreshed."""
+        a = i32(np.asarray(actions).reshape(self.batch, self.n))
+        g = None if gauss is None else f64(np.asarray(gauss).reshape(self.batch, self.n))
+        if out_states is None:
+            out_states = np.empty((self.batch, self.n), dtype=WorldToy.STATE_DTYPE)
+        if out_rewards is None:
+            out_rewards = np.empty((self.batch, self.n))
+        assert out_states.dtype == WorldToy.STATE_DTYPE and out_states.flags.c_contiguous
+        assert out_rewards.dtype == np.float64 and out_rewards.flags.c_contiguous
+        check(lib().epi_world_step(self._h, ptr(a, C.c_int32), ptr(g, C.c_double) if g is not None else None,
+                                   C.c_int32(self.base.t_max if t_max is None else t_max),
+                                   C.cast(out_states.ctypes.data, C.POINTER(_capi.CState)), ptr(out_rewards, C.c_double)))
+        return out_states, out_rewards
+
+    def set_timing(self, on: bool):
+        check(lib().epi_world_set_timing(self._h, C.c_int32(int(on))))
+
+    def kernel_time(self):
+        """(summed episode-kernel ms, launches, country-steps) since timing was switched on."""
+        ms = C.c_double(0); k = C.c_int64(0); cs = C.c_int64(0)
+        check(lib().epi_world_kernel_time(self._h, C.byref(ms), C.byref(k), C.byref(cs)))
+        return ms.value, k.value, cs.value
 
     def set_mlp(self, W1, W2, W3, b1=None, b2=None, b3=None, clip_q=None):
         W1, W2, W3 = f64(W1), f64(W2), f64(W3)

@@ -85,6 +85,27 @@ struct DevBuf {
     T* as() const { return static_cast<T*>(p); }
 };
 
+// Owning page-locked host allocation (staging for the per-step transfers of the batched worlds).
+struct PinBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    hipError_t ensure(size_t want) {
+        if (want <= bytes && p) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; bytes = 0;
+        if (want == 0) want = 16;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    template <class T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
 const epi_profile kDefaultProfile = {1.0, 1.0, 0.05, 100.0, 30000.0, 0.7, 0.15, 0.8, 0.7};  // Geo.scala:4-21
 
 Hyper to_hyper(const epi_hyper& h) {
@@ -459,9 +480,21 @@ struct epi_world {
     bool mlp_set = false;
     EpisodeBuffers work;
     DevBuf act_dev, gauss_dev, reward_dev, flow_s, flow_i, q_tmp;
+    // compact [batch][n] images of the caller's arrays: device side and page-locked host side
+    DevBuf in_act, in_gauss, out_states, out_rewards, out_actions;
+    PinBuf pin_act, pin_gauss, pin_states, pin_rewards, pin_actions, pin_err;
     std::vector<JavaRandom> env_rnd;  // one stream per country (env.scala:42)
     std::vector<int32_t> env_seeds;
     bool have_flows = false;
+    // optional timing of the episode kernel (HIP events on the launch stream)
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double kernel_ms = 0.0;
+    long long kernel_launches = 0, kernel_country_steps = 0;
+    ~epi_world() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
 };
 
 // ================================================================================================
@@ -1045,6 +1078,19 @@ static int32_t world_build(epi_world* Wd, const epi_world_desc* d) {
     HIP_TRY(Wd->reward_dev.ensure(cells * sizeof(double)));
     HIP_TRY(Wd->flow_s.ensure(cells * sizeof(int32_t)));
     HIP_TRY(Wd->flow_i.ensure(cells * sizeof(int32_t)));
+    if (cells > (size_t)1 << 30) return fail(EPI_ERR_UNSUPPORTED, "world: batch x padded countries = %zu exceeds 2^30 cells", cells);
+    const size_t compact = (size_t)d->batch * n;
+    HIP_TRY(Wd->in_act.ensure(compact * sizeof(int32_t)));
+    HIP_TRY(Wd->in_gauss.ensure(compact * sizeof(double)));
+    HIP_TRY(Wd->out_states.ensure(compact * sizeof(epi_state)));
+    HIP_TRY(Wd->out_rewards.ensure(compact * sizeof(double)));
+    HIP_TRY(Wd->out_actions.ensure(compact * sizeof(int32_t)));
+    HIP_TRY(Wd->pin_act.ensure(compact * sizeof(int32_t)));
+    HIP_TRY(Wd->pin_gauss.ensure(compact * sizeof(double)));
+    HIP_TRY(Wd->pin_states.ensure(compact * sizeof(epi_state)));
+    HIP_TRY(Wd->pin_rewards.ensure(compact * sizeof(double)));
+    HIP_TRY(Wd->pin_actions.ensure(compact * sizeof(int32_t)));
+    HIP_TRY(Wd->pin_err.ensure((size_t)d->batch * 4 * sizeof(int32_t)));
     return EPI_OK;
 }
 
@@ -1082,24 +1128,24 @@ EPI_API int32_t epi_world_reset(epi_world* w) {
     return world_init_states(w);
 }
 
+static void world_io_args(const epi_world* w, WorldIoArgs& io) {
+    io.n = w->n; io.npad = w->npad; io.batch = w->batch;
+    io.act_pad = w->act_dev.as<int8_t>(); io.gauss_pad = w->gauss_dev.as<double>();
+    io.err = w->work.err.as<int32_t>();
+    io.st = w->work.st.as<int32_t>(); io.cap = w->work.cap.as<double>(); io.tcur = w->work.tcur.as<int32_t>();
+    io.reward_pad = w->reward_dev.as<double>();
+    io.base = w->base;
+}
+
 static int32_t world_download_states(epi_world* w, epi_state* out) {
-    const int n = w->n, npad = w->npad, B = w->batch;
-    const size_t cells = (size_t)B * npad;
-    std::vector<int32_t> st(cells * 5), tc(cells);
-    std::vector<double> cap(cells);
-    HIP_TRY(hipMemcpy(st.data(), w->work.st.p, st.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(tc.data(), w->work.tcur.p, tc.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(cap.data(), w->work.cap.p, cap.size() * sizeof(double), hipMemcpyDeviceToHost));
-    for (int b = 0; b < B; ++b)
-        for (int c = 0; c < n; ++c) {
-            const size_t idx = (size_t)b * npad + c;
-            epi_state& o = out[(size_t)b * n + c];
-            o = w->base;
-            o.s = st[0 * cells + idx]; o.i = st[1 * cells + idx]; o.r = st[2 * cells + idx];
-            o.d = st[3 * cells + idx]; o.v = st[4 * cells + idx];
-            o.hosp_cap = cap[idx];
-            o.t = tc[idx];
-        }
+    WorldIoArgs io{};
+    world_io_args(w, io);
+    io.states_out = w->out_states.as<epi_state>();
+    const size_t bytes = (size_t)w->batch * w->n * sizeof(epi_state);
+    HIP_TRY(launch_world_unpack(io, nullptr));
+    HIP_TRY(hipMemcpyAsync(w->pin_states.p, w->out_states.p, bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    std::memcpy(out, w->pin_states.p, bytes);
     return EPI_OK;
 }
 
@@ -1146,26 +1192,34 @@ EPI_API int32_t epi_world_set_mlp(epi_world* w, int32_t hidden, const double* W1
 static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy, const double* gauss, int32_t t_max,
                                epi_state* out_states, double* out_rewards, int32_t* out_actions) {
     const int n = w->n, npad = w->npad, B = w->batch;
-    const size_t cells = (size_t)B * npad;
+    const size_t cells = (size_t)B * npad, compact = (size_t)B * n;
     HIP_TRY(hipSetDevice(w->device));
+    if (greedy && !w->mlp_set) return fail(EPI_ERR_BAD_ARGUMENT, "world greedy step: call epi_world_set_mlp first");
+    hipStream_t s = nullptr;
+    WorldIoArgs io{};
+    world_io_args(w, io);
     // noise draws: caller-supplied, or one JVM-compatible stream per country shared by all instances
-    std::vector<double> hz(cells, 0.0);
+    double* hz = w->pin_gauss.as<double>();
     if (gauss) {
-        for (int b = 0; b < B; ++b)
-            for (int c = 0; c < n; ++c) {
-                const double z = gauss[(size_t)b * n + c];
-                if (!std::isfinite(z)) return fail(EPI_ERR_BAD_ARGUMENT, "world step: gauss[%d][%d] is not finite", b, c);
-                hz[(size_t)b * npad + c] = z;
-            }
-    } else {
-        for (int c = 0; c < n; ++c) {
-            const double z = w->env_rnd[c].nextGaussian();
-            for (int b = 0; b < B; ++b) hz[(size_t)b * npad + c] = z;
+        for (size_t k = 0; k < compact; ++k) {
+            if (!std::isfinite(gauss[k]))
+                return fail(EPI_ERR_BAD_ARGUMENT, "world step: gauss[%d][%d] is not finite", (int)(k / n), (int)(k % n));
+            hz[k] = gauss[k];
         }
+        HIP_TRY(hipMemcpyAsync(w->in_gauss.p, hz, compact * sizeof(double), hipMemcpyHostToDevice, s));
+        io.gauss = w->in_gauss.as<double>();
+    } else {
+        for (int c = 0; c < n; ++c) hz[c] = w->env_rnd[c].nextGaussian();
+        HIP_TRY(hipMemcpyAsync(w->in_gauss.p, hz, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+        io.gauss_row = w->in_gauss.as<double>();
     }
-    HIP_TRY(hipMemcpy(w->gauss_dev.p, hz.data(), cells * sizeof(double), hipMemcpyHostToDevice));
+    if (!greedy) {
+        std::memcpy(w->pin_act.p, actions, compact * sizeof(int32_t));
+        HIP_TRY(hipMemcpyAsync(w->in_act.p, w->pin_act.p, compact * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        io.actions = w->in_act.as<int32_t>();
+    }
+    HIP_TRY(launch_world_pack(io, s));
     if (greedy) {
-        if (!w->mlp_set) return fail(EPI_ERR_BAD_ARGUMENT, "world greedy step: call epi_world_set_mlp first");
         MlpArgs ma{};
         ma.rows = B * n; ma.n = n; ma.npad = npad;
         ma.state_t_max = w->base.t_max;
@@ -1173,15 +1227,7 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
         ma.plane = cells;
         w->mlp.fill(ma);
         ma.act_episode = w->act_dev.as<int8_t>();
-        HIP_TRY(launch_mlp(ma, nullptr));
-    } else {
-        std::vector<int8_t> ha(cells, 0);
-        for (int b = 0; b < B; ++b)
-            for (int c = 0; c < n; ++c) {
-                const int32_t a = actions[(size_t)b * n + c];
-                ha[(size_t)b * npad + c] = (int8_t)(a < 0 ? 0 : (a > 7 ? 7 : a));  // Action.fromId clamps
-            }
-        HIP_TRY(hipMemcpy(w->act_dev.p, ha.data(), cells, hipMemcpyHostToDevice));
+        HIP_TRY(launch_mlp(ma, s));
     }
     EpisodeArgs ea{};
     ea.n = n; ea.npad = npad; ea.count = B;
@@ -1200,28 +1246,38 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
     ea.arrival = w->work.arrival.as<int32_t>(); ea.peak = w->work.peak.as<int32_t>(); ea.err = w->work.err.as<int32_t>();
     ea.rwd = w->rwd.as<RewardConsts>(); ea.reward_out = w->reward_dev.as<double>();
     ea.flow_s = w->flow_s.as<int32_t>(); ea.flow_i = w->flow_i.as<int32_t>();
-    HIP_TRY(hipMemset(w->work.err.p, 0, (size_t)B * 4 * sizeof(int32_t)));
-    HIP_TRY(launch_episode(ea, nullptr));
-    HIP_TRY(hipDeviceSynchronize());
+    if (w->timing) HIP_TRY(hipEventRecord(w->ev0, s));
+    HIP_TRY(launch_episode(ea, s));
+    if (w->timing) HIP_TRY(hipEventRecord(w->ev1, s));
+    // results: compact on the device, then one transfer per requested array into page-locked memory
+    if (out_states) io.states_out = w->out_states.as<epi_state>();
+    if (out_rewards) io.rewards_out = w->out_rewards.as<double>();
+    if (out_actions) io.actions_out = w->out_actions.as<int32_t>();
+    if (out_states || out_rewards || out_actions) HIP_TRY(launch_world_unpack(io, s));
+    HIP_TRY(hipMemcpyAsync(w->pin_err.p, w->work.err.p, (size_t)B * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (out_states)
+        HIP_TRY(hipMemcpyAsync(w->pin_states.p, w->out_states.p, compact * sizeof(epi_state), hipMemcpyDeviceToHost, s));
+    if (out_rewards)
+        HIP_TRY(hipMemcpyAsync(w->pin_rewards.p, w->out_rewards.p, compact * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (out_actions)
+        HIP_TRY(hipMemcpyAsync(w->pin_actions.p, w->out_actions.p, compact * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (w->timing) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, w->ev0, w->ev1));
+        w->kernel_ms += ms;
+        w->kernel_launches += 1;
+        w->kernel_country_steps += (long long)B * n;
+    }
     w->have_flows = true;
-    int32_t rc = collect_errors(w->work.err, B, 0);
-    if (rc) return rc;
-    if (out_states) {
-        rc = world_download_states(w, out_states);
-        if (rc) return rc;
-    }
-    if (out_rewards) {
-        std::vector<double> hr(cells);
-        HIP_TRY(hipMemcpy(hr.data(), w->reward_dev.p, cells * sizeof(double), hipMemcpyDeviceToHost));
-        for (int b = 0; b < B; ++b)
-            for (int c = 0; c < n; ++c) out_rewards[(size_t)b * n + c] = hr[(size_t)b * npad + c];
-    }
-    if (out_actions) {
-        std::vector<int8_t> ha(cells);
-        HIP_TRY(hipMemcpy(ha.data(), w->act_dev.p, cells, hipMemcpyDeviceToHost));
-        for (int b = 0; b < B; ++b)
-            for (int c = 0; c < n; ++c) out_actions[(size_t)b * n + c] = ha[(size_t)b * npad + c];
-    }
+    const int32_t* he = w->pin_err.as<int32_t>();
+    for (int e = 0; e < B; ++e)
+        if (he[(size_t)e * 4] != 0)
+            return fail(he[(size_t)e * 4], "%s (instance %d, country %d, t=%d)", status_text(he[(size_t)e * 4]), e,
+                        he[(size_t)e * 4 + 1], he[(size_t)e * 4 + 2]);
+    if (out_states) std::memcpy(out_states, w->pin_states.p, compact * sizeof(epi_state));
+    if (out_rewards) std::memcpy(out_rewards, w->pin_rewards.p, compact * sizeof(double));
+    if (out_actions) std::memcpy(out_actions, w->pin_actions.p, compact * sizeof(int32_t));
     return EPI_OK;
 }
 
@@ -1235,6 +1291,26 @@ EPI_API int32_t epi_world_step_greedy(epi_world* w, const double* gauss, int32_t
                                       double* out_rewards, int32_t* out_actions) {
     if (!w) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_step_greedy: null handle");
     return world_step_impl(w, nullptr, true, gauss, t_max, out_states, out_rewards, out_actions);
+}
+
+EPI_API int32_t epi_world_set_timing(epi_world* w, int32_t on) {
+    if (!w) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_set_timing: null handle");
+    HIP_TRY(hipSetDevice(w->device));
+    if (on && !w->ev0) {
+        HIP_TRY(hipEventCreate(&w->ev0));
+        HIP_TRY(hipEventCreate(&w->ev1));
+    }
+    w->timing = on != 0;
+    if (on) { w->kernel_ms = 0.0; w->kernel_launches = 0; w->kernel_country_steps = 0; }
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_world_kernel_time(epi_world* w, double* total_ms, int64_t* launches, int64_t* country_steps) {
+    if (!w) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_kernel_time: null handle");
+    if (total_ms) *total_ms = w->kernel_ms;
+    if (launches) *launches = w->kernel_launches;
+    if (country_steps) *country_steps = w->kernel_country_steps;
+    return EPI_OK;
 }
 
 EPI_API int32_t epi_world_last_flows(epi_world* w, int32_t* moved_s, int32_t* moved_i) {

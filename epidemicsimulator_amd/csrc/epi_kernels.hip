@@ -789,4 +789,67 @@ hipError_t launch_env_batch(const EnvBatchArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batched worlds: the caller's arrays are compact [batch][n]; the episode kernels work on planes
+// padded to npad columns.  pack spreads actions (clamped as Action.fromId, env.scala:18-20) and
+// noise draws over the planes and clears the error table; unpack gathers State records
+// (env.scala:22-25), rewards and the chosen actions back into compact arrays.
+// ---------------------------------------------------------------------------------------------
+__global__ void world_pack_kernel(const WorldIoArgs a) {
+    const int cells = a.batch * a.n;
+    const int stride = gridDim.x * blockDim.x;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cells || k < a.batch * 4; k += stride) {
+        if (k < a.batch * 4) a.err[k] = 0;
+        if (k >= cells) continue;
+        const int b = k / a.n, c = k - b * a.n;
+        const size_t o = (size_t)b * a.npad + c;
+        if (a.actions) {
+            const int32_t act = a.actions[k];
+            a.act_pad[o] = (int8_t)(act < 0 ? 0 : (act > 7 ? 7 : act));
+        }
+        a.gauss_pad[o] = a.gauss ? a.gauss[k] : a.gauss_row[c];
+    }
+}
+
+__global__ void world_unpack_kernel(const WorldIoArgs a) {
+    const int cells = a.batch * a.n;
+    const size_t plane = (size_t)a.batch * a.npad;
+    const int stride = gridDim.x * blockDim.x;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cells; k += stride) {
+        const int b = k / a.n, c = k - b * a.n;
+        const size_t o = (size_t)b * a.npad + c;
+        if (a.states_out) {
+            epi_state s = a.base;
+            s.s = (double)a.st[0 * plane + o];
+            s.i = (double)a.st[1 * plane + o];
+            s.r = (double)a.st[2 * plane + o];
+            s.d = (double)a.st[3 * plane + o];
+            s.v = (double)a.st[4 * plane + o];
+            s.hosp_cap = a.cap[o];
+            s.t = a.tcur[o];
+            a.states_out[k] = s;
+        }
+        if (a.rewards_out) a.rewards_out[k] = a.reward_pad[o];
+        if (a.actions_out) a.actions_out[k] = (int32_t)a.act_pad[o];
+    }
+}
+
+static unsigned io_blocks(int items) {
+    const long long b = ((long long)items + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+hipError_t launch_world_pack(const WorldIoArgs& a, hipStream_t s) {
+    if (a.batch <= 0) return hipSuccess;
+    const int items = a.batch * (a.n > 4 ? a.n : 4);
+    hipLaunchKernelGGL(world_pack_kernel, dim3(io_blocks(items)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_world_unpack(const WorldIoArgs& a, hipStream_t s) {
+    if (a.batch <= 0) return hipSuccess;
+    hipLaunchKernelGGL(world_unpack_kernel, dim3(io_blocks(a.batch * a.n)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 }  // namespace epi

@@ -112,6 +112,26 @@ struct EnvBatchArgs {
     const double* gauss; epi_state* out; double* reward; uint8_t* done;
 };
 
+// Compact caller-side arrays [batch][n] <-> the padded per-instance planes [batch][npad] of the episode kernels.
+struct WorldIoArgs {
+    int n, npad, batch;
+    // pack: caller inputs -> padded planes (also clears the error table)
+    const int32_t* actions;   // [batch][n] or NULL (greedy step: the network kernel writes act_pad)
+    const double* gauss;      // [batch][n] or NULL
+    const double* gauss_row;  // [n] one draw per country shared by all instances (used when gauss == NULL)
+    int8_t* act_pad;          // [batch][npad]
+    double* gauss_pad;        // [batch][npad]
+    int32_t* err;             // [batch][4]
+    // unpack: padded planes -> caller outputs (each optional)
+    const int32_t* st; const double* cap; const int32_t* tcur; const double* reward_pad;
+    epi_state base;           // t_max, seed copied into every state
+    epi_state* states_out;    // [batch][n]
+    double* rewards_out;      // [batch][n]
+    int32_t* actions_out;     // [batch][n]
+};
+
+hipError_t launch_world_pack(const WorldIoArgs& a, hipStream_t s);
+hipError_t launch_world_unpack(const WorldIoArgs& a, hipStream_t s);
 hipError_t launch_episode(const EpisodeArgs& a, hipStream_t s);
 hipError_t launch_init(const InitArgs& a, hipStream_t s);
 hipError_t launch_loss(const LossArgs& a, hipStream_t s);

@@ -196,6 +196,9 @@ int32_t epi_world_set_states(epi_world *w, const epi_state *in);  /* restoreStat
 int32_t epi_world_reset(epi_world *w);                            /* resetToInitial :77 */
 /* Net S and I flows of the last step, movedS/movedI[batch][n] (WorldToy.scala:106-126). */
 int32_t epi_world_last_flows(epi_world *w, int32_t *moved_s, int32_t *moved_i);
+/* Measurement hooks (no counterpart in the reference), as epi_grid_set_timing / epi_grid_kernel_time. */
+int32_t epi_world_set_timing(epi_world *w, int32_t on);
+int32_t epi_world_kernel_time(epi_world *w, double *total_ms, int64_t *launches, int64_t *country_steps);
 int32_t epi_world_destroy(epi_world *w);
 
 #ifdef __cplusplus
