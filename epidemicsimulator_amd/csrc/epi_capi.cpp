@@ -195,6 +195,7 @@ struct GraphTables {
     std::vector<int32_t> h_slots, h_off;  // ELL block tables
     std::vector<int32_t> h_rowptr, h_col;
     std::vector<double> h_val;
+    std::vector<double> h_ell_q;          // host copy of the ELL weights (seed-block variants are cut from it)
 
     // Normalises one stored row in column order: the reference sums the full row left to right, and
     // adding the zeros of the entries that are not stored changes no partial sum.
@@ -280,8 +281,9 @@ struct GraphTables {
             h_off[b] = total_slots;
             total_slots += dmax;
         }
-        std::vector<double> eq((size_t)(total_slots > 0 ? total_slots : 1) * 64, 0.0);
-        std::vector<int32_t> ec((size_t)(total_slots > 0 ? total_slots : 1) * 64, -1);
+        // padded by one row length: the kernel reads whole groups of slots, also past a block's last slot
+        std::vector<double> eq((size_t)(total_slots + kLaneSlots) * 64, 0.0);
+        std::vector<int32_t> ec((size_t)(total_slots + kLaneSlots) * 64, -1);
         for (int i = 0; i < n; ++i) {
             const int b = i / 64, l = i % 64, rs = h_rowptr[i], deg = h_rowptr[i + 1] - rs;
             if (deg > kLaneSlots) continue;  // long rows stay empty in the lane layout
@@ -306,6 +308,7 @@ struct GraphTables {
         HIP_TRY(d_off.upload(h_off));
         HIP_TRY(d_col.upload(ec));
         HIP_TRY(d_qval.upload(eq));
+        h_ell_q.swap(eq);
         HIP_TRY(sumw.upload(hs));
         HIP_TRY(pop.upload(hp));
         return EPI_OK;
@@ -691,10 +694,13 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
         const int rs = G->graph.h_rowptr[d->seed_idx], deg = G->graph.h_rowptr[d->seed_idx + 1] - rs;
         const int nt = d->n_travel > 0 ? d->n_travel : 1;
         const bool seed_long = deg > kLaneSlots;
-        // the lane of the seed row reads its block's slots; a long seed row is read as 64 padded slots
-        const int slots = seed_long ? 64 : std::max(1, G->graph.h_slots[d->seed_idx / 64]);
+        // a long seed row is read by one wave as 64 padded slots; otherwise the whole 64-row block of the
+        // seed row is copied once per travel scale (kLaneSlots slots each) with that one row replaced
+        const int slots = seed_long ? 64 : kLaneSlots;
+        const int sb = d->seed_idx / 64, sl = d->seed_idx % 64;
         G->seed_long = seed_long ? 1 : 0;
-        std::vector<double> hq((size_t)nt * slots, 0.0), hs((size_t)nt, 0.0), row((size_t)(deg > 0 ? deg : 1));
+        std::vector<double> hq((size_t)nt * slots * (seed_long ? 1 : 64), 0.0), hs((size_t)nt, 0.0), row((size_t)(deg > 0 ? deg : 1));
+        std::vector<double> qrow((size_t)64, 0.0);
         for (int k = 0; k < d->n_travel; ++k) {
             if (!std::isfinite(d->travel[k]) || d->travel[k] < 0.0) return fail(EPI_ERR_BAD_ARGUMENT, "grid: travel scale %d = %g", k, d->travel[k]);
             double s = 0.0;
@@ -708,8 +714,18 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
                 for (int e = 0; e < deg; ++e)
                     if (G->graph.h_col[rs + e] != d->seed_idx) row[e] *= sc;
             }
-            rc = GraphTables::normalise_sparse_row(row.data(), G->graph.h_col.data() + rs, deg, d->seed_idx, &hq[(size_t)k * slots], &hs[k]);
+            std::fill(qrow.begin(), qrow.end(), 0.0);
+            rc = GraphTables::normalise_sparse_row(row.data(), G->graph.h_col.data() + rs, deg, d->seed_idx, qrow.data(), &hs[k]);
             if (rc) return rc;
+            if (seed_long) {
+                std::copy(qrow.begin(), qrow.end(), hq.begin() + (size_t)k * 64);
+            } else {
+                double* blk = &hq[(size_t)k * slots * 64];
+                const int bs = G->graph.h_slots[sb];
+                for (int e = 0; e < bs; ++e)
+                    for (int l = 0; l < 64; ++l) blk[(size_t)e * 64 + l] = G->graph.h_ell_q[((size_t)G->graph.h_off[sb] + e) * 64 + l];
+                for (int e = 0; e < slots; ++e) blk[(size_t)e * 64 + sl] = e < deg ? qrow[e] : 0.0;
+            }
         }
         G->seed_deg = slots;
         HIP_TRY(G->qseed.upload(hq));

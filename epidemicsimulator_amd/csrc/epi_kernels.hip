@@ -1,6 +1,7 @@
 // HIP kernels (gfx950) for the metapopulation step and the calibration sweep.
 // Compiled with -ffp-contract=off: see epi_device.hpp.
 #include "epi_kernels.hpp"
+#include "sort_net.hpp"
 
 namespace epi {
 using namespace dev;
@@ -222,8 +223,9 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
 // slot-major (ELL) layout -- slot k of the 64 rows of a block is contiguous -- so that the 64 lanes
 // of a wave read their k-th weights with one coalesced load.  Every lane runs the same
 // largest-remainder split as the dense kernel on its own short row, entirely in its registers:
-// high words of the fractions as keys, a threshold K with #{key >= K} = rem found by bracketing,
-// ties in the high word finished exactly on the full fractions in ascending column order.
+// high words of the fractions as keys, the threshold K = the rem-th largest key taken from a copy
+// sorted by a sorting network, ties in the high word finished exactly on the full fractions in
+// ascending column order.
 //
 // Entries that are not stored have weight 0, hence raw = 0, base = 0 and fraction 0: they could only
 // receive a unit after every positive fraction has one.  For finite non-negative weights
@@ -233,23 +235,50 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
 // ---------------------------------------------------------------------------------------------
 constexpr int kCsrThreads = 768;  // 8 waves: room for a whole row of keys per lane without spilling
 
+// Slots are read in groups of kSlotGroup: a group is skipped when the block has no such slots,
+// and all loads of the groups that are read are issued before the first one is consumed.  The
+// ELL arrays are padded so that every slot of a group that starts below D can be read.
+constexpr int kSlotGroup = 8;
+
+// Address of slot k0 of a lane's row, formed where it is used: the empty asm keeps the compiler from
+// precomputing one 64-bit address per slot ahead of the loops, which costs two registers per slot;
+// the slots of a group are then reached with immediate offsets.
+template <class T>
+__device__ __forceinline__ const T* group_ptr(const T* p, int k0) {
+    const T* g = p + k0 * 64;
+    asm volatile("" : "+v"(g));
+    return g;
+}
+
 template <int DMAX>
-__device__ __forceinline__ void lane_apportion(int32_t E, int D, const double* __restrict__ qp, int qstride,
+__device__ __forceinline__ void lane_apportion(int32_t E, int D, const double* __restrict__ qp,
                                                const int32_t* __restrict__ cp, int row, uint32_t* sh_mov, int* sh_err,
                                                int t) {
+    static_assert(DMAX % kSlotGroup == 0, "slot groups");
     const double Ed = (double)E;
-    uint32_t key[DMAX];
-    uint32_t bsum = 0u, pos = 0u, kmax = 0u;
+    uint32_t key[DMAX], srt[DMAX];
+    uint32_t bsum = 0u, pos = 0u;
+    {
+        double qv[DMAX];
 #pragma unroll
-    for (int k = 0; k < DMAX; ++k) {
-        key[k] = 0u;
-        if (k < D) {
-            const double raw = qp[(size_t)k * qstride] * Ed;
+        for (int k0 = 0; k0 < DMAX; k0 += kSlotGroup) {
+#pragma unroll
+            for (int j = 0; j < kSlotGroup; ++j) qv[k0 + j] = 0.0;
+            if (k0 < D) {
+                const double* qg = group_ptr(qp, k0);
+#pragma unroll
+                for (int j = 0; j < kSlotGroup; ++j) qv[k0 + j] = qg[j * 64];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) {
+            const double raw = qv[k] * Ed;
             const double fr = frac_of(raw);
-            bsum += (uint32_t)(int32_t)raw;
-            key[k] = (uint32_t)__double2hiint(fr);
-            pos += (fr > 0.0);
-            kmax = max(kmax, key[k]);
+            const bool in = k < D;
+            bsum += in ? (uint32_t)(int32_t)raw : 0u;
+            key[k] = in ? (uint32_t)__double2hiint(fr) : 0u;
+            pos += (in && fr > 0.0);
+            srt[k] = key[k];
         }
     }
     int32_t rem = E > 0 ? (int32_t)((uint32_t)E - bsum) : 0;
@@ -257,61 +286,75 @@ __device__ __forceinline__ void lane_apportion(int32_t E, int D, const double* _
         record_error(sh_err, EPI_ERR_UNSUPPORTED, row, t);
         rem = 0;
     }
-    // per-lane bracket: #{key >= lo} = clo > rem > chi = #{key >= hi}; padding slots hold key 0 and
-    // every probe is >= 1, so they are never counted
-    uint32_t lo = 0u, hi = kmax + 1u, K = 0u;
-    int clo = D, chi = 0, it = 0;
-    bool found = false;
-    bool active = rem > 0;
-    while (active) {
-        uint32_t mid;
-        if ((it & 3) == 3) {
-            mid = lo + ((hi - lo) >> 1);
-        } else {
-            const float f = ((float)(clo - rem) + 0.5f) * __builtin_amdgcn_rcpf((float)(clo - chi + 1));
-            const double vlo = from_hi_word(lo), vhi = from_hi_word(hi);
-            mid = (uint32_t)__double2hiint(vlo + (vhi - vlo) * (double)f);
-        }
-        mid = max(mid, lo + 1u);
-        mid = min(mid, hi - 1u);
-        int c = 0;
+    // threshold K = the rem-th largest key, read from a sorted copy (sorting network, no data-dependent
+    // control flow, so 64 different rows cost the same as one); `nxt` = the key ranked right below it
+    sort_desc<DMAX>(srt);
+    uint32_t K = 0u, nxt = 0u;
 #pragma unroll
-        for (int k = 0; k < DMAX; ++k) c += (key[k] >= mid);
-        ++it;
-        if (c == rem) { found = true; K = mid; active = false; }
-        else if (c > rem) { lo = mid; clo = c; }
-        else { hi = mid; chi = c; }
-        if (hi - lo <= 1u) active = false;
+    for (int j = 0; j < DMAX; ++j) {
+        K = (j == rem - 1) ? srt[j] : K;
+        nxt = (j == rem) ? srt[j] : nxt;
     }
-    // tie in the high word `lo`: pick m = rem - chi of its members by (fraction descending, column
-    // ascending), one at a time; members are few unless weights repeat
-    unsigned long long picked = 0ull;
+    // the high words of ranks rem and rem+1 differ: every key >= K is selected.  Otherwise the tie in
+    // high word K is finished on the full fractions: m = rem - #{key > K} of its members by (fraction
+    // descending, column ascending), one at a time; members are few unless weights repeat
+    const bool found = rem > 0 && (rem == DMAX || nxt != K);
     const bool tie = rem > 0 && !found;
+    unsigned long long picked = 0ull;
     if (__any(tie)) {
-        int m = tie ? rem - chi : 0;
+        int above = 0;
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) above += (key[k] > K);
+        int m = tie ? rem - above : 0;
         while (__any(m > 0)) {
             double best = -1.0;
             int best_k = -1;
 #pragma unroll
-            for (int k = 0; k < DMAX; ++k) {
-                if (k < D) {
-                    const double fr = frac_of(qp[(size_t)k * qstride] * Ed);
-                    const bool cand = m > 0 && key[k] == lo && !((picked >> k) & 1ull) && fr > best;
-                    if (cand) { best = fr; best_k = k; }
+            for (int k0 = 0; k0 < DMAX; k0 += kSlotGroup) {
+                if (k0 < D) {
+                    const double* qg = group_ptr(qp, k0);
+#pragma unroll
+                    for (int j = 0; j < kSlotGroup; ++j) {
+                        const int k = k0 + j;
+                        const double fr = frac_of(qg[j * 64] * Ed);
+                        const bool cand = k < D && m > 0 && key[k] == K && !((picked >> k) & 1ull) && fr > best;
+                        if (cand) { best = fr; best_k = k; }
+                    }
                 }
             }
             if (m > 0 && best_k >= 0) picked |= 1ull << best_k;
             m -= 1;
         }
     }
+    constexpr int HALF = DMAX / 2;
 #pragma unroll
-    for (int k = 0; k < DMAX; ++k) {
-        if (k < D) {
-            const double raw = qp[(size_t)k * qstride] * Ed;
-            const bool sel = found ? (key[k] >= K) : (tie && (key[k] > lo || ((picked >> k) & 1ull)));
-            const uint32_t alloc = (uint32_t)(int32_t)raw + (uint32_t)sel;
-            const int col = cp[(size_t)k * 64];
-            if (E > 0 && alloc != 0u && col >= 0 && col != row) atomicAdd(&sh_mov[col], alloc);
+    for (int h0 = 0; h0 < DMAX; h0 += HALF) {
+        if (h0 < D) {
+            double qv[HALF];
+            int cv[HALF];
+#pragma unroll
+            for (int k0 = 0; k0 < HALF; k0 += kSlotGroup) {
+#pragma unroll
+                for (int j = 0; j < kSlotGroup; ++j) { qv[k0 + j] = 0.0; cv[k0 + j] = -1; }
+                if (h0 + k0 < D) {
+                    const double* qg = group_ptr(qp, h0 + k0);
+                    const int32_t* cg = group_ptr(cp, h0 + k0);
+#pragma unroll
+                    for (int j = 0; j < kSlotGroup; ++j) {
+                        qv[k0 + j] = qg[j * 64];
+                        cv[k0 + j] = cg[j * 64];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < HALF; ++j) {
+                const int k = h0 + j;
+                const double raw = qv[j] * Ed;
+                const bool sel = found ? (key[k] >= K) : (tie && (key[k] > K || ((picked >> k) & 1ull)));
+                const uint32_t alloc = (uint32_t)(int32_t)raw + (uint32_t)sel;
+                const int col = cv[j];
+                if (k < D && E > 0 && alloc != 0u && col >= 0 && col != row) atomicAdd(&sh_mov[col], alloc);
+            }
         }
     }
 }
@@ -409,17 +452,20 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 const bool valid = row < n && a.rowptr[row + 1] - a.rowptr[row] <= kLaneSlots;
                 const int32_t ES = valid ? expS[row] : 0, EI = valid ? expI[row] : 0;
                 if (!__any((ES | EI) != 0)) continue;
-                const int D = a.ell_slots[b];
-                const size_t off = (size_t)a.ell_off[b] * 64 + lane;
-                const double* __restrict__ qp = a.qval + off;
-                int qstride = 64;
-                if (row == a.seed_idx && a.qval_seed && !a.seed_long) {
-                    qp = a.qval_seed + (size_t)ti * a.seed_deg;
-                    qstride = 1;
+                const int D = __builtin_amdgcn_readfirstlane(a.ell_slots[b]);  // same for the whole block
+                if (D <= 0) continue;
+                const size_t off = (size_t)__builtin_amdgcn_readfirstlane(a.ell_off[b]) * 64;
+                // the block of the seed row has one copy per travel scale (only that row differs)
+                const double* __restrict__ qp =
+                    (b == (a.seed_idx >> 6) && a.qval_seed && !a.seed_long)
+                        ? a.qval_seed + (size_t)ti * a.seed_deg * 64 + lane
+                        : a.qval + off + lane;
+                const int32_t* __restrict__ cp = a.col + off + lane;
+#pragma nounroll
+                for (int comp = 0; comp < 2; ++comp) {  // one copy of the routine for S and I
+                    const int32_t E = comp ? EI : ES;
+                    if (__any(E > 0)) lane_apportion<DMAX>(E, D, qp, cp, row, comp ? sh_movI : sh_movS, sh_err, t);
                 }
-                const int32_t* __restrict__ cp = a.col + off;
-                if (__any(ES > 0)) lane_apportion<DMAX>(ES, D, qp, qstride, cp, row, sh_movS, sh_err, t);
-                if (__any(EI > 0)) lane_apportion<DMAX>(EI, D, qp, qstride, cp, row, sh_movI, sh_err, t);
             }
             // the few rows longer than kLaneSlots: one wave per row with the dense kernel's routine on
             // the compact row (64 slots, zero padded), scattered through the row's column list
@@ -432,12 +478,12 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 const double* __restrict__ qrow =
                     (row == a.seed_idx && a.qval_seed) ? a.qval_seed + (size_t)ti * a.seed_deg : a.long_q + (size_t)o * 64;
                 const int col = a.long_col[(size_t)o * 64 + lane];
-                uint32_t accS[1] = {0u}, accI[1] = {0u};
-                if (ES > 0) apportion_row<1>(ES, deg, -1, qrow, accS, lane, nullptr);
-                if (EI > 0) apportion_row<1>(EI, deg, -1, qrow, accI, lane, nullptr);
-                if (col >= 0 && col != row) {
-                    if (accS[0]) atomicAdd(&sh_movS[col], accS[0]);
-                    if (accI[0]) atomicAdd(&sh_movI[col], accI[0]);
+#pragma nounroll
+                for (int comp = 0; comp < 2; ++comp) {
+                    const int32_t E = comp ? EI : ES;
+                    uint32_t acc[1] = {0u};
+                    if (E > 0) apportion_row<1>(E, deg, -1, qrow, acc, lane, nullptr);
+                    if (col >= 0 && col != row && acc[0]) atomicAdd(comp ? &sh_movI[col] : &sh_movS[col], acc[0]);
                 }
             }
         }
@@ -502,6 +548,7 @@ hipError_t launch_episode(const EpisodeArgs& a, hipStream_t s) {
     if (a.rowptr) {
         if (csr_lds_bytes(a.n) > kMaxLdsBytes) return hipErrorInvalidValue;
         if (a.max_deg <= 16) return launch_csr<16>(a, s);
+        if (a.max_deg <= 24) return launch_csr<24>(a, s);
         if (a.max_deg <= kLaneSlots) return launch_csr<kLaneSlots>(a, s);
         return hipErrorInvalidValue;
     }

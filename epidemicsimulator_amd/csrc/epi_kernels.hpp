@@ -36,10 +36,12 @@ struct EpisodeArgs {
     const int32_t* rowptr;    // [n+1] (marks sparse mode; row lengths)
     const int32_t* ell_slots; // [ceil(n/64)]
     const int32_t* ell_off;   // [ceil(n/64)]
-    const int32_t* col;       // ELL columns, ascending inside a row, -1 = padding
+    const int32_t* col;       // ELL columns, ascending inside a row, -1 = padding; col and qval end with kLaneSlots
+                              // slots of padding so that whole slot groups can be read
     const double* qval;       // ELL normalised weights w_ij / sumW_i (a stored diagonal entry holds 0)
-    const double* qval_seed;  // [n_travel][seed_deg] seed-row variants, zero padded to the block's slots
-    int seed_deg, max_deg;    // stride of qval_seed; longest row held in the lane layout
+    const double* qval_seed;  // per travel scale: a copy [seed_deg][64] of the seed row's block with that row replaced,
+                              // or, when the seed row is a long row, the row itself [seed_deg = 64]
+    int seed_deg, max_deg;    // slots per variant in qval_seed; longest row held in the lane layout
     int seed_long;            // the seed row is one of the long rows below
     int n_long;               // rows longer than kLaneSlots: compact copies, 64 slots each
     const int32_t* long_rows; // [n_long]
