@@ -190,7 +190,7 @@ struct GraphTables {
     // sparse mode (n > kMaxDenseN): CSR arrays on the device, raw weights on the host
     bool sparse = false;
     int max_deg = 0, lane_deg = 0;
-    DevBuf d_rowptr, d_col, d_qval, d_slots, d_off, d_long_rows, d_long_q, d_long_col;
+    DevBuf d_rowptr, d_col, d_qval, d_ell, d_long_rows, d_long_q, d_long_col;
     std::vector<int32_t> h_long_rows;     // rows longer than kLaneSlots
     std::vector<int32_t> h_slots, h_off;  // ELL block tables
     std::vector<int32_t> h_rowptr, h_col;
@@ -279,11 +279,10 @@ struct GraphTables {
             lane_deg = std::max(lane_deg, dmax);
             h_slots[b] = dmax;
             h_off[b] = total_slots;
-            total_slots += dmax;
+            total_slots += (dmax + kSlotGroup - 1) / kSlotGroup * kSlotGroup;  // whole slot groups, zero filled
         }
-        // padded by one row length: the kernel reads whole groups of slots, also past a block's last slot
-        std::vector<double> eq((size_t)(total_slots + kLaneSlots) * 64, 0.0);
-        std::vector<int32_t> ec((size_t)(total_slots + kLaneSlots) * 64, -1);
+        std::vector<double> eq((size_t)(total_slots > 0 ? total_slots : 1) * 64, 0.0);
+        std::vector<int32_t> ec((size_t)(total_slots > 0 ? total_slots : 1) * 64, -1);
         for (int i = 0; i < n; ++i) {
             const int b = i / 64, l = i % 64, rs = h_rowptr[i], deg = h_rowptr[i + 1] - rs;
             if (deg > kLaneSlots) continue;  // long rows stay empty in the lane layout
@@ -304,8 +303,14 @@ struct GraphTables {
         HIP_TRY(d_long_q.upload(lq));
         HIP_TRY(d_long_col.upload(lc));
         HIP_TRY(d_rowptr.upload(h_rowptr));
-        HIP_TRY(d_slots.upload(h_slots));
-        HIP_TRY(d_off.upload(h_off));
+        std::vector<EllBlock> hb((size_t)nblocks);
+        for (int b = 0; b < nblocks; ++b) {
+            hb[b].slots = h_slots[b];
+            hb[b].off = h_off[b];
+            hb[b].long_mask = 0ull;
+        }
+        for (int i : h_long_rows) hb[i / 64].long_mask |= 1ull << (i % 64);
+        HIP_TRY(d_ell.upload(hb));
         HIP_TRY(d_col.upload(ec));
         HIP_TRY(d_qval.upload(eq));
         h_ell_q.swap(eq);
@@ -319,7 +324,7 @@ struct GraphTables {
         if (sparse) {
             ea.q = nullptr; ea.qtop = nullptr;
             ea.rowptr = d_rowptr.as<int32_t>(); ea.col = d_col.as<int32_t>(); ea.qval = d_qval.as<double>();
-            ea.ell_slots = d_slots.as<int32_t>(); ea.ell_off = d_off.as<int32_t>();
+            ea.ell = d_ell.as<EllBlock>();
             ea.max_deg = lane_deg;
             ea.n_long = (int)h_long_rows.size();
             ea.long_rows = d_long_rows.as<int32_t>(); ea.long_q = d_long_q.as<double>(); ea.long_col = d_long_col.as<int32_t>();
@@ -855,6 +860,7 @@ EPI_API int32_t epi_grid_destroy(epi_grid* g) {
                 for (int b = 0; b < 28; ++b) fprintf(stderr, " %llu", s[4 + b]);
                 fprintf(stderr, "\n");
             }
+            fprintf(stderr, "[epi cycles] pass1 %llu select %llu pass2 %llu | A %llu barA %llu B %llu barB %llu C %llu\n", h[48], h[49], h[50], h[51], h[52], h[53], h[54], h[55]);
         }
     }
     delete g;

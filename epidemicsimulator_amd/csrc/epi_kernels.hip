@@ -3,8 +3,20 @@
 #include "epi_kernels.hpp"
 #include "sort_net.hpp"
 
+// Phase timers of the sparse kernel: compiled in with -DEPI_CSR_TIMERS (they cost registers), read with EPI_STATS=1.
+#ifdef EPI_CSR_TIMERS
+#define EPI_TM(...) __VA_ARGS__
+#else
+#define EPI_TM(...)
+#endif
+
 namespace epi {
 using namespace dev;
+
+template <class T>
+__device__ __forceinline__ void keep_loaded(T& x) {
+    asm volatile("" : "+v"(x));
+}
 
 // WorldToy.scala:115: min(X.toLong, floor(X * sumW + 1e-9).toLong).toInt for X >= 0, sumW >= 0.
 __device__ __forceinline__ int32_t export_count(int32_t X, double sumW) {
@@ -235,76 +247,52 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
 // ---------------------------------------------------------------------------------------------
 constexpr int kCsrThreads = 768;  // 8 waves: room for a whole row of keys per lane without spilling
 
-// Slots are read in groups of kSlotGroup: a group is skipped when the block has no such slots,
-// and all loads of the groups that are read are issued before the first one is consumed.  The
-// ELL arrays are padded so that every slot of a group that starts below D can be read.
-constexpr int kSlotGroup = 8;
+// Slots are read in groups of kSlotGroup: a group is skipped when the block has no such slots, and all
+// loads of the groups that are read are issued before the first one is consumed.  Every block's slot
+// count is rounded up to whole groups in the ELL arrays, the extra slots holding weight 0.
 
 // Address of slot k0 of a lane's row, formed where it is used: the empty asm keeps the compiler from
 // precomputing one 64-bit address per slot ahead of the loops, which costs two registers per slot;
 // the slots of a group are then reached with immediate offsets.
 template <class T>
 __device__ __forceinline__ const T* group_ptr(const T* p, int k0) {
-    const T* g = p + k0 * 64;
-    asm volatile("" : "+v"(g));
-    return g;
+    int off = k0 * 64;
+    asm volatile("" : "+v"(off));
+    return p + off;
 }
 
+// Threshold of one compartment of one lane's row: the rem largest of the keys (high words of the
+// fractions of q * E) are those with key >= Kx, plus the slots whose bit is set in `picked` (ties in
+// the high word of the rem-th largest key, finished on the full fractions by (fraction descending,
+// column ascending)).  `srt` holds the keys on entry and is consumed; the keys are cheap to form again
+// from the weights, which is what the rare tie path and the scatter pass do instead of keeping them.
+struct LaneThreshold {
+    uint32_t Kx, picked;
+};
+
 template <int DMAX>
-__device__ __forceinline__ void lane_apportion(int32_t E, int D, const double* __restrict__ qp,
-                                               const int32_t* __restrict__ cp, int row, uint32_t* sh_mov, int* sh_err,
-                                               int t) {
-    static_assert(DMAX % kSlotGroup == 0, "slot groups");
-    const double Ed = (double)E;
-    uint32_t key[DMAX], srt[DMAX];
-    uint32_t bsum = 0u, pos = 0u;
-    {
-        double qv[DMAX];
-#pragma unroll
-        for (int k0 = 0; k0 < DMAX; k0 += kSlotGroup) {
-#pragma unroll
-            for (int j = 0; j < kSlotGroup; ++j) qv[k0 + j] = 0.0;
-            if (k0 < D) {
-                const double* qg = group_ptr(qp, k0);
-#pragma unroll
-                for (int j = 0; j < kSlotGroup; ++j) qv[k0 + j] = qg[j * 64];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < DMAX; ++k) {
-            const double raw = qv[k] * Ed;
-            const double fr = frac_of(raw);
-            const bool in = k < D;
-            bsum += in ? (uint32_t)(int32_t)raw : 0u;
-            key[k] = in ? (uint32_t)__double2hiint(fr) : 0u;
-            pos += (in && fr > 0.0);
-            srt[k] = key[k];
-        }
-    }
-    int32_t rem = E > 0 ? (int32_t)((uint32_t)E - bsum) : 0;
-    if (rem > (int32_t)pos) {
-        record_error(sh_err, EPI_ERR_UNSUPPORTED, row, t);
-        rem = 0;
-    }
-    // threshold K = the rem-th largest key, read from a sorted copy (sorting network, no data-dependent
-    // control flow, so 64 different rows cost the same as one); `nxt` = the key ranked right below it
+__device__ __forceinline__ LaneThreshold lane_threshold(uint32_t (&srt)[DMAX], int32_t rem, double Ed, int D,
+                                                        const double* __restrict__ qp) {
+    // K = the rem-th largest key, read from the sorted keys (sorting network: no data-dependent control
+    // flow, so 64 different rows cost the same as one); `nxt` = the key ranked right below it
     sort_desc<DMAX>(srt);
     uint32_t K = 0u, nxt = 0u;
 #pragma unroll
     for (int j = 0; j < DMAX; ++j) {
-        K = (j == rem - 1) ? srt[j] : K;
-        nxt = (j == rem) ? srt[j] : nxt;
+        const bool hit = (j == rem - 1);
+        K = hit ? srt[j] : K;
+        if (j + 1 < DMAX) nxt = hit ? srt[j + 1] : nxt;
     }
-    // the high words of ranks rem and rem+1 differ: every key >= K is selected.  Otherwise the tie in
-    // high word K is finished on the full fractions: m = rem - #{key > K} of its members by (fraction
-    // descending, column ascending), one at a time; members are few unless weights repeat
+    // ranks rem and rem+1 differ in the high word: every key >= K is selected.  Otherwise m = rem - #{key > K}
+    // members of the tie are picked one at a time; they are few unless weights repeat
     const bool found = rem > 0 && (rem == DMAX || nxt != K);
     const bool tie = rem > 0 && !found;
-    unsigned long long picked = 0ull;
+    LaneThreshold r;
+    r.picked = 0u;
     if (__any(tie)) {
         int above = 0;
 #pragma unroll
-        for (int k = 0; k < DMAX; ++k) above += (key[k] > K);
+        for (int j = 0; j < DMAX; ++j) above += (srt[j] > K);
         int m = tie ? rem - above : 0;
         while (__any(m > 0)) {
             double best = -1.0;
@@ -317,16 +305,76 @@ __device__ __forceinline__ void lane_apportion(int32_t E, int D, const double* _
                     for (int j = 0; j < kSlotGroup; ++j) {
                         const int k = k0 + j;
                         const double fr = frac_of(qg[j * 64] * Ed);
-                        const bool cand = k < D && m > 0 && key[k] == K && !((picked >> k) & 1ull) && fr > best;
+                        const bool cand = k < D && m > 0 && (uint32_t)__double2hiint(fr) == K && !((r.picked >> k) & 1u) && fr > best;
                         if (cand) { best = fr; best_k = k; }
                     }
                 }
             }
-            if (m > 0 && best_k >= 0) picked |= 1ull << best_k;
+            if (m > 0 && best_k >= 0) r.picked |= 1u << best_k;
             m -= 1;
         }
     }
-    constexpr int HALF = DMAX / 2;
+    // keys are high words of fractions below 1, far from 2^32 - 1: the sentinel selects nothing
+    r.Kx = found ? K : (tie ? K + 1u : 0xffffffffu);
+    return r;
+}
+
+// Mobility split of one block of 64 rows, one lane per row, S and I in one sweep over the block's weights
+// (each weight is read twice per step: once for the keys, once with its column for the scatter).
+// A lane that exports nothing in a compartment runs along with E = 0: every product is 0, nothing is selected.
+template <int DMAX>
+__device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI, int D, const double* __restrict__ qp,
+                                               const int32_t* __restrict__ cp, int row, uint32_t* sh_movS,
+                                               uint32_t* sh_movI, int* sh_err, int t, long long* tm) {
+    static_assert(DMAX % kSlotGroup == 0, "whole slot groups");
+    // slots are worked on in chunks of whole groups: all loads of a chunk are in flight together
+    constexpr int HALF = (DMAX % (2 * kSlotGroup) == 0) ? DMAX / 2 : kSlotGroup;
+    const double EdS = (double)ES, EdI = (double)EI;
+    uint32_t keyS[DMAX], keyI[DMAX];
+    uint32_t bsumS = 0u, bsumI = 0u, posS = 0u, posI = 0u;
+    EPI_TM(long long c0 = clock64();)
+#pragma unroll
+    for (int h0 = 0; h0 < DMAX; h0 += HALF) {
+        double qv[HALF];
+#pragma unroll
+        for (int k0 = 0; k0 < HALF; k0 += kSlotGroup) {
+#pragma unroll
+            for (int j = 0; j < kSlotGroup; ++j) qv[k0 + j] = 0.0;
+            if (h0 + k0 < D) {
+                const double* qg = group_ptr(qp, h0 + k0);
+#pragma unroll
+                for (int j = 0; j < kSlotGroup; ++j) qv[k0 + j] = qg[j * 64];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) {
+            const int k = h0 + j;
+            const double rawS = qv[j] * EdS;  // slots past D of a group that is read hold weight 0
+            const double frS = frac_of(rawS);
+            bsumS += (uint32_t)(int32_t)rawS;
+            keyS[k] = (uint32_t)__double2hiint(frS);
+            posS += (frS > 0.0);
+            const double rawI = qv[j] * EdI;
+            const double frI = frac_of(rawI);
+            bsumI += (uint32_t)(int32_t)rawI;
+            keyI[k] = (uint32_t)__double2hiint(frI);
+            posI += (frI > 0.0);
+        }
+    }
+    int32_t remS = (int32_t)((uint32_t)ES - bsumS), remI = (int32_t)((uint32_t)EI - bsumI);
+    if (remS > (int32_t)posS || remI > (int32_t)posI) {
+        record_error(sh_err, EPI_ERR_UNSUPPORTED, row, t);
+        remS = remI = 0;
+    }
+    EPI_TM(asm volatile("" ::"v"(remS), "v"(remI)); { const long long c1 = clock64(); tm[0] += c1 - c0; c0 = c1; })
+    const LaneThreshold thS = lane_threshold<DMAX>(keyS, remS, EdS, D, qp);
+    LaneThreshold thI;
+    thI.Kx = 0xffffffffu;
+    thI.picked = 0u;
+    if (anyI) thI = lane_threshold<DMAX>(keyI, remI, EdI, D, qp);
+    EPI_TM(asm volatile("" ::"v"(thS.Kx), "v"(thI.Kx)); { const long long c1 = clock64(); tm[1] += c1 - c0; c0 = c1; })
+    // A unit lands only on stored off-diagonal entries: padding and a stored diagonal hold weight 0, hence
+    // base 0 and fraction 0, and fractions that are 0 are never selected (rem <= #positive fractions).
 #pragma unroll
     for (int h0 = 0; h0 < DMAX; h0 += HALF) {
         if (h0 < D) {
@@ -335,7 +383,7 @@ __device__ __forceinline__ void lane_apportion(int32_t E, int D, const double* _
 #pragma unroll
             for (int k0 = 0; k0 < HALF; k0 += kSlotGroup) {
 #pragma unroll
-                for (int j = 0; j < kSlotGroup; ++j) { qv[k0 + j] = 0.0; cv[k0 + j] = -1; }
+                for (int j = 0; j < kSlotGroup; ++j) { qv[k0 + j] = 0.0; cv[k0 + j] = 0; }
                 if (h0 + k0 < D) {
                     const double* qg = group_ptr(qp, h0 + k0);
                     const int32_t* cg = group_ptr(cp, h0 + k0);
@@ -349,14 +397,18 @@ __device__ __forceinline__ void lane_apportion(int32_t E, int D, const double* _
 #pragma unroll
             for (int j = 0; j < HALF; ++j) {
                 const int k = h0 + j;
-                const double raw = qv[j] * Ed;
-                const bool sel = found ? (key[k] >= K) : (tie && (key[k] > K || ((picked >> k) & 1ull)));
-                const uint32_t alloc = (uint32_t)(int32_t)raw + (uint32_t)sel;
-                const int col = cv[j];
-                if (k < D && E > 0 && alloc != 0u && col >= 0 && col != row) atomicAdd(&sh_mov[col], alloc);
+                const double rawS = qv[j] * EdS;
+                const uint32_t selS = (uint32_t)((uint32_t)__double2hiint(frac_of(rawS)) >= thS.Kx) | ((thS.picked >> k) & 1u);
+                const uint32_t allocS = (uint32_t)(int32_t)rawS + selS;
+                if (allocS != 0u) atomicAdd(&sh_movS[cv[j]], allocS);
+                const double rawI = qv[j] * EdI;
+                const uint32_t selI = (uint32_t)((uint32_t)__double2hiint(frac_of(rawI)) >= thI.Kx) | ((thI.picked >> k) & 1u);
+                const uint32_t allocI = (uint32_t)(int32_t)rawI + selI;
+                if (allocI != 0u) atomicAdd(&sh_movI[cv[j]], allocI);
             }
         }
     }
+    EPI_TM(__builtin_amdgcn_s_waitcnt(0); { const long long c1 = clock64(); tm[2] += c1 - c0; })
 }
 
 template <int DMAX>
@@ -392,11 +444,17 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
     }
     __syncthreads();
 
+    long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // per-wave cycle counts by phase (EPI_CSR_TIMERS builds)
     for (int t = a.t_begin; t < a.t_end; ++t) {
         const int par = t & 1;
+        EPI_TM(long long k0 = clock64();)
         // ------------------------------------------------------------------ phase A: local dynamics
         unsigned long long mass_local = 0ull;
-        for (int c = tid; c < n; c += kCsrThreads) {
+        for (int cc = tid; cc < n; cc += kCsrThreads) {
+            // the index is made opaque: otherwise one 64-bit address per array is precomputed ahead of the
+            // step loop and kept (spilled) for the whole kernel
+            int c = cc;
+            asm volatile("" : "+v"(c));
             StepConsts k;
             k.beta0 = a.beta0[(size_t)bi * NP + c];
             k.gamma = a.cst[CST_GAMMA * NP + c];
@@ -413,6 +471,10 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
             const double z = a.noise_episode ? a.noise_episode[eoff + c] : a.noise[(size_t)(t - a.noise_t0) * NP + c];
             const int32_t s0 = st_s[c], i0 = st_i[c], r0 = st_r[c], d0 = st_d[c], v0 = st_v[c];
             const int32_t tc = a.tcur[eoff + c];
+            // every constant is fetched with the state, in one batch: left alone, the loads of those that only
+            // some actions use sink into the action branches, one exposed memory latency each
+            keep_loaded(k.eff1); keep_loaded(k.eff2); keep_loaded(k.eff3); keep_loaded(k.surge);
+            keep_loaded(k.vax6); keep_loaded(k.vax7); keep_loaded(k.ifr0); keep_loaded(k.cnoise);
             const long long tb = (long long)s0 + i0 + r0 + d0 + v0;
             const LocalOut o = local_step(k, s0, i0, r0, d0, v0, a.cap[eoff + c], act, z);
             const long long ta = (long long)o.s + o.i + o.r + o.d + o.v;
@@ -434,7 +496,9 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
             const unsigned long long wsum = wave_sum_u64(mass_local);
             if (lane == 0) atomicAdd(&sh_mass[par * 2 + 0], wsum);
         }
+        EPI_TM(__builtin_amdgcn_s_waitcnt(0); { const long long k1 = clock64(); tm[3] += k1 - k0; k0 = k1; })
         __syncthreads();
+        EPI_TM({ const long long k1 = clock64(); tm[4] += k1 - k0; k0 = k1; })
 
         // ------------------------------------------------------------------ phase B: mobility
         if (tid == 0 && a.validate && t > a.t_begin) {
@@ -444,28 +508,35 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
             sh_mass[p * 2 + 1] = 0ull;
         }
         {
-            const int wave = tid >> 6;
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
             const int nblocks = (n + 63) >> 6;
-            for (int b = wave; b < nblocks; b += kCsrThreads / 64) {
+            // the exports and the block record of the next block are fetched while the current one is worked on
+            int b = wave;
+            EllBlock blk = a.ell[b < nblocks ? b : 0];
+            int32_t ES = expS[(b < nblocks ? b : 0) * 64 + lane], EI = expI[(b < nblocks ? b : 0) * 64 + lane];
+            for (; b < nblocks; b += kCsrThreads / 64) {
                 const int row = b * 64 + lane;
+                const EllBlock cur = blk;
                 // rows longer than kLaneSlots are empty in the lane layout and handled below
-                const bool valid = row < n && a.rowptr[row + 1] - a.rowptr[row] <= kLaneSlots;
-                const int32_t ES = valid ? expS[row] : 0, EI = valid ? expI[row] : 0;
-                if (!__any((ES | EI) != 0)) continue;
-                const int D = __builtin_amdgcn_readfirstlane(a.ell_slots[b]);  // same for the whole block
+                const bool valid = row < n && !((cur.long_mask >> lane) & 1ull);
+                const int32_t ESc = valid ? ES : 0, EIc = valid ? EI : 0;
+                {
+                    const int bn = b + kCsrThreads / 64 < nblocks ? b + kCsrThreads / 64 : b;
+                    blk = a.ell[bn];
+                    ES = expS[bn * 64 + lane];
+                    EI = expI[bn * 64 + lane];
+                }
+                if (!__any((ESc | EIc) != 0)) continue;
+                const int D = __builtin_amdgcn_readfirstlane(cur.slots);  // same for the whole block
                 if (D <= 0) continue;
-                const size_t off = (size_t)__builtin_amdgcn_readfirstlane(a.ell_off[b]) * 64;
+                const size_t off = (size_t)__builtin_amdgcn_readfirstlane(cur.off) * 64;
                 // the block of the seed row has one copy per travel scale (only that row differs)
                 const double* __restrict__ qp =
                     (b == (a.seed_idx >> 6) && a.qval_seed && !a.seed_long)
                         ? a.qval_seed + (size_t)ti * a.seed_deg * 64 + lane
                         : a.qval + off + lane;
                 const int32_t* __restrict__ cp = a.col + off + lane;
-#pragma nounroll
-                for (int comp = 0; comp < 2; ++comp) {  // one copy of the routine for S and I
-                    const int32_t E = comp ? EI : ES;
-                    if (__any(E > 0)) lane_apportion<DMAX>(E, D, qp, cp, row, comp ? sh_movI : sh_movS, sh_err, t);
-                }
+                lane_apportion<DMAX>(ESc, EIc, __any(EIc > 0), D, qp, cp, row, sh_movS, sh_movI, sh_err, t, tm);
             }
             // the few rows longer than kLaneSlots: one wave per row with the dense kernel's routine on
             // the compact row (64 slots, zero padded), scattered through the row's column list
@@ -487,11 +558,15 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 }
             }
         }
+        EPI_TM({ const long long k1 = clock64(); tm[5] += k1 - k0; k0 = k1; })
         __syncthreads();
+        EPI_TM({ const long long k1 = clock64(); tm[6] += k1 - k0; k0 = k1; })
 
         // ------------------------------------------------------------------ phase C: apply
         unsigned long long mass_move = 0ull;
-        for (int c = tid; c < n; c += kCsrThreads) {
+        for (int cc = tid; cc < n; cc += kCsrThreads) {
+            int c = cc;
+            asm volatile("" : "+v"(c));
             const int32_t movedS = (int32_t)(sh_movS[c] - (uint32_t)expS[c]);
             const int32_t movedI = (int32_t)(sh_movI[c] - (uint32_t)expI[c]);
             const double ns = fmax(0.0, (double)st_s[c] + (double)movedS);
@@ -516,7 +591,9 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
             if (lane == 0) atomicAdd(&sh_mass[par * 2 + 1], wsum);
         }
         // patch c is read here and re-initialised in the next phase A by the same thread: no barrier
+        EPI_TM(__builtin_amdgcn_s_waitcnt(0); { const long long k1 = clock64(); tm[7] += k1 - k0; })
     }
+    EPI_TM(if (a.stats && lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&a.stats[48 + i], (unsigned long long)tm[i]);)
     __syncthreads();
     if (tid == 0) {
         if (a.validate && a.t_end > a.t_begin) {

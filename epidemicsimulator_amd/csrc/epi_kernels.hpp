@@ -13,6 +13,7 @@ constexpr int kMaxDenseN = kMaxDenseR * 64;  // widest dense row held in one wav
 constexpr size_t kMaxLdsBytes = 160 * 1024;  // LDS of one CU: bounds the patches of a sparse world
 constexpr int kMaxSparseDegree = 64;          // longest stored row the sparse kernel apportions
 constexpr int kLaneSlots = 32;                // longest row a single lane keeps in registers
+constexpr int kSlotGroup = 8;                 // ELL blocks are stored in whole groups of this many slots
 size_t csr_lds_bytes(int n);
 
 // Indices into the per-country constant table cst[k][npad] (StepConsts minus beta0).
@@ -20,6 +21,13 @@ enum { CST_GAMMA = 0, CST_IFR0, CST_CNOISE, CST_EFF1, CST_EFF2, CST_EFF3, CST_SU
 
 // One launch of the fused dense episode kernel: steps [t_begin, t_end) of `count` episodes, one
 // workgroup per episode, npad threads (one per padded country, one wave per 64).
+// One block of 64 consecutive rows of a sparse graph in the slot-major layout.
+struct EllBlock {
+    int32_t slots;                 // longest row of the block that is kept in the lane layout
+    int32_t off;                   // first slot of the block in col / qval (in units of 64 entries)
+    unsigned long long long_mask;  // bit l set: row 64*b + l is longer than kLaneSlots and handled as a long row
+};
+
 struct EpisodeArgs {
     int n, npad, count;
     int seed_idx, n_travel;  // travel variant of the seed row: (g_begin + e) % n_travel; < 0 = none
@@ -32,12 +40,11 @@ struct EpisodeArgs {
     const double* qseed;     // [n_travel][npad] seed-row variants (ToyConn.scaleRow per travel scale)
     const double* sumw_seed; // [n_travel]
     // sparse graphs (rowptr != NULL): rows in blocks of 64, slot-major (ELL) inside a block: slot k of
-    // row 64*b + l is element (ell_off[b] + k) * 64 + l of col / qval; ell_slots[b] = longest row of the block
+    // row 64*b + l is element (ell[b].off + k) * 64 + l of col / qval
     const int32_t* rowptr;    // [n+1] (marks sparse mode; row lengths)
-    const int32_t* ell_slots; // [ceil(n/64)]
-    const int32_t* ell_off;   // [ceil(n/64)]
-    const int32_t* col;       // ELL columns, ascending inside a row, -1 = padding; col and qval end with kLaneSlots
-                              // slots of padding so that whole slot groups can be read
+    const EllBlock* ell;      // [ceil(n/64)]
+    const int32_t* col;       // ELL columns, ascending inside a row, -1 = padding; every block occupies a whole
+                              // number of slot groups (kSlotGroup), the extra slots holding weight 0
     const double* qval;       // ELL normalised weights w_ij / sumW_i (a stored diagonal entry holds 0)
     const double* qval_seed;  // per travel scale: a copy [seed_deg][64] of the seed row's block with that row replaced,
                               // or, when the seed row is a long row, the row itself [seed_deg = 64]
