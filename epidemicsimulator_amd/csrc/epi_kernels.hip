@@ -444,154 +444,182 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
     }
     __syncthreads();
 
-    long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // per-wave cycle counts by phase (EPI_CSR_TIMERS builds)
-    for (int t = a.t_begin; t < a.t_end; ++t) {
-        const int par = t & 1;
+    int* sh_next = &sh_err[3];  // work queue of the mobility phase: next block or long row to hand out
+    const int nblocks = (n + 63) >> 6;
+    EPI_TM(long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};)  // per-wave cycle counts by phase
+#ifndef EPI_CSR_TIMERS
+    long long* tm = nullptr;
+#endif
+    // Step t: local dynamics (A), barrier, mobility (B), barrier, apply (C).  A thread owns the same patches
+    // in A and C, so C of step t-1 and A of step t run as one pass over the thread's patches: the state of a
+    // patch is read once and written once per step.
+    for (int t = a.t_begin; t <= a.t_end; ++t) {
+        const bool doC = t > a.t_begin, doA = t < a.t_end;
         EPI_TM(long long k0 = clock64();)
-        // ------------------------------------------------------------------ phase A: local dynamics
-        unsigned long long mass_local = 0ull;
+        if (tid == 0) *sh_next = 0;
+        unsigned long long mass_local = 0ull, mass_move = 0ull;
         for (int cc = tid; cc < n; cc += kCsrThreads) {
             // the index is made opaque: otherwise one 64-bit address per array is precomputed ahead of the
             // step loop and kept (spilled) for the whole kernel
             int c = cc;
             asm volatile("" : "+v"(c));
+            int32_t s0 = st_s[c], i0 = st_i[c];
+            const int32_t r0 = st_r[c], d0 = st_d[c], v0 = st_v[c];
+            int32_t tc = a.tcur[eoff + c];
             StepConsts k;
-            k.beta0 = a.beta0[(size_t)bi * NP + c];
-            k.gamma = a.cst[CST_GAMMA * NP + c];
-            k.ifr0 = a.cst[CST_IFR0 * NP + c];
-            k.cnoise = a.cst[CST_CNOISE * NP + c];
-            k.eff1 = a.cst[CST_EFF1 * NP + c];
-            k.eff2 = a.cst[CST_EFF2 * NP + c];
-            k.eff3 = a.cst[CST_EFF3 * NP + c];
-            k.surge = a.cst[CST_SURGE * NP + c];
-            k.vax6 = a.cst[CST_VAX6 * NP + c];
-            k.vax7 = a.cst[CST_VAX7 * NP + c];
-            int act = a.act_episode ? (int)a.act_episode[eoff + c] : (int)a.actions[(size_t)(t - a.act_t0) * NP + c];
-            act = act < 0 ? 0 : (act > 7 ? 7 : act);
-            const double z = a.noise_episode ? a.noise_episode[eoff + c] : a.noise[(size_t)(t - a.noise_t0) * NP + c];
-            const int32_t s0 = st_s[c], i0 = st_i[c], r0 = st_r[c], d0 = st_d[c], v0 = st_v[c];
-            const int32_t tc = a.tcur[eoff + c];
-            // every constant is fetched with the state, in one batch: left alone, the loads of those that only
-            // some actions use sink into the action branches, one exposed memory latency each
-            keep_loaded(k.eff1); keep_loaded(k.eff2); keep_loaded(k.eff3); keep_loaded(k.surge);
-            keep_loaded(k.vax6); keep_loaded(k.vax7); keep_loaded(k.ifr0); keep_loaded(k.cnoise);
-            const long long tb = (long long)s0 + i0 + r0 + d0 + v0;
-            const LocalOut o = local_step(k, s0, i0, r0, d0, v0, a.cap[eoff + c], act, z);
-            const long long ta = (long long)o.s + o.i + o.r + o.d + o.v;
-            if (a.validate && ta != tb) record_error(sh_err, EPI_ERR_LOCAL_MASS, c, tc);
-            if ((o.s | o.i | o.r | o.d | o.v) < 0) record_error(sh_err, EPI_ERR_INT_RANGE, c, tc);
-            if (a.rwd) a.reward_out[eoff + c] = reward_of(a.rwd[c], (double)i0, (double)d0, o, act);
-            st_s[c] = o.s; st_i[c] = o.i; st_r[c] = o.r; st_d[c] = o.d; st_v[c] = o.v;
-            a.cap[eoff + c] = o.cap;
-            a.tcur[eoff + c] = tc + 1;
-            const double sw = (c == a.seed_idx && a.qval_seed) ? a.sumw_seed[ti] : a.sumw[c];
-            expS[c] = export_count(max(0, o.s), sw);
-            expI[c] = export_count(max(0, o.i), sw);
-            sh_movS[c] = 0u;
-            sh_movI[c] = 0u;
-            mass_local += ta > 0 ? (unsigned long long)ta : 0ull;
+            int act = 0;
+            double z = 0.0, cap0 = 0.0, sw = 0.0;
+            if (doA) {
+                k.beta0 = a.beta0[(size_t)bi * NP + c];
+                k.gamma = a.cst[CST_GAMMA * NP + c];
+                k.ifr0 = a.cst[CST_IFR0 * NP + c];
+                k.cnoise = a.cst[CST_CNOISE * NP + c];
+                k.eff1 = a.cst[CST_EFF1 * NP + c];
+                k.eff2 = a.cst[CST_EFF2 * NP + c];
+                k.eff3 = a.cst[CST_EFF3 * NP + c];
+                k.surge = a.cst[CST_SURGE * NP + c];
+                k.vax6 = a.cst[CST_VAX6 * NP + c];
+                k.vax7 = a.cst[CST_VAX7 * NP + c];
+                act = a.act_episode ? (int)a.act_episode[eoff + c] : (int)a.actions[(size_t)(t - a.act_t0) * NP + c];
+                act = act < 0 ? 0 : (act > 7 ? 7 : act);
+                z = a.noise_episode ? a.noise_episode[eoff + c] : a.noise[(size_t)(t - a.noise_t0) * NP + c];
+                cap0 = a.cap[eoff + c];
+                sw = (c == a.seed_idx && a.qval_seed) ? a.sumw_seed[ti] : a.sumw[c];
+                // every constant is fetched with the state, in one batch: left alone, the loads of those that only
+                // some actions use sink into the action branches, one exposed memory latency each
+                keep_loaded(k.eff1); keep_loaded(k.eff2); keep_loaded(k.eff3); keep_loaded(k.surge);
+                keep_loaded(k.vax6); keep_loaded(k.vax7); keep_loaded(k.ifr0); keep_loaded(k.cnoise);
+            }
+            if (doC) {  // ---- phase C of step t-1 (WorldToy.scala:128-145)
+                const int32_t movedS = (int32_t)(sh_movS[c] - (uint32_t)expS[c]);
+                const int32_t movedI = (int32_t)(sh_movI[c] - (uint32_t)expI[c]);
+                const int32_t arr = a.arrival[eoff + c], pk = a.peak[eoff + c];
+                const double ns = fmax(0.0, (double)s0 + (double)movedS);
+                const double ni = fmax(0.0, (double)i0 + (double)movedI);
+                if (ns > 2147483647.0 || ni > 2147483647.0) record_error(sh_err, EPI_ERR_INT_RANGE, c, tc);
+                s0 = (int32_t)ns;
+                i0 = (int32_t)ni;
+                tc = min(tc + 1, a.step_t_max);
+                if (arr < 0 && i0 >= 10) a.arrival[eoff + c] = t - 1;
+                if (i0 > pk) a.peak[eoff + c] = i0;
+                if (a.flow_s) {
+                    a.flow_s[eoff + c] = movedS;
+                    a.flow_i[eoff + c] = movedI;
+                }
+                const long long tmv = (long long)s0 + i0 + r0 + d0 + v0;
+                mass_move += tmv > 0 ? (unsigned long long)tmv : 0ull;
+            }
+            if (doA) {  // ---- phase A of step t (WorldToy.scala:83-104)
+                const long long tb = (long long)s0 + i0 + r0 + d0 + v0;
+                const LocalOut o = local_step(k, s0, i0, r0, d0, v0, cap0, act, z);
+                const long long ta = (long long)o.s + o.i + o.r + o.d + o.v;
+                if (a.validate && ta != tb) record_error(sh_err, EPI_ERR_LOCAL_MASS, c, tc);
+                if ((o.s | o.i | o.r | o.d | o.v) < 0) record_error(sh_err, EPI_ERR_INT_RANGE, c, tc);
+                if (a.rwd) a.reward_out[eoff + c] = reward_of(a.rwd[c], (double)i0, (double)d0, o, act);
+                st_s[c] = o.s; st_i[c] = o.i; st_r[c] = o.r; st_d[c] = o.d; st_v[c] = o.v;
+                a.cap[eoff + c] = o.cap;
+                a.tcur[eoff + c] = tc + 1;
+                expS[c] = export_count(max(0, o.s), sw);
+                expI[c] = export_count(max(0, o.i), sw);
+                sh_movS[c] = 0u;
+                sh_movI[c] = 0u;
+                mass_local += ta > 0 ? (unsigned long long)ta : 0ull;
+            } else {
+                st_s[c] = s0;
+                st_i[c] = i0;
+                a.tcur[eoff + c] = tc;
+            }
         }
         if (a.validate) {
             // per-thread partial sums stay below 2^44 (at most 40 patches of < 2^34 each per thread)
-            const unsigned long long wsum = wave_sum_u64(mass_local);
-            if (lane == 0) atomicAdd(&sh_mass[par * 2 + 0], wsum);
+            if (doC) {
+                const unsigned long long wsum = wave_sum_u64(mass_move);
+                if (lane == 0) atomicAdd(&sh_mass[((t - 1) & 1) * 2 + 1], wsum);
+            }
+            if (doA) {
+                const unsigned long long wsum = wave_sum_u64(mass_local);
+                if (lane == 0) atomicAdd(&sh_mass[(t & 1) * 2 + 0], wsum);
+            }
         }
+        if (!doA) break;
         EPI_TM(__builtin_amdgcn_s_waitcnt(0); { const long long k1 = clock64(); tm[3] += k1 - k0; k0 = k1; })
         __syncthreads();
         EPI_TM({ const long long k1 = clock64(); tm[4] += k1 - k0; k0 = k1; })
 
         // ------------------------------------------------------------------ phase B: mobility
-        if (tid == 0 && a.validate && t > a.t_begin) {
+        if (tid == 0 && a.validate && doC) {
             const int p = (t - 1) & 1;
             if (sh_mass[p * 2] != sh_mass[p * 2 + 1]) record_error(sh_err, EPI_ERR_WORLD_MASS, -1, t - 1);
             sh_mass[p * 2] = 0ull;
             sh_mass[p * 2 + 1] = 0ull;
         }
         {
-            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-            const int nblocks = (n + 63) >> 6;
-            // the exports and the block record of the next block are fetched while the current one is worked on
-            int b = wave;
-            EllBlock blk = a.ell[b < nblocks ? b : 0];
-            int32_t ES = expS[(b < nblocks ? b : 0) * 64 + lane], EI = expI[(b < nblocks ? b : 0) * 64 + lane];
-            for (; b < nblocks; b += kCsrThreads / 64) {
-                const int row = b * 64 + lane;
-                const EllBlock cur = blk;
-                // rows longer than kLaneSlots are empty in the lane layout and handled below
-                const bool valid = row < n && !((cur.long_mask >> lane) & 1ull);
-                const int32_t ESc = valid ? ES : 0, EIc = valid ? EI : 0;
-                {
-                    const int bn = b + kCsrThreads / 64 < nblocks ? b + kCsrThreads / 64 : b;
-                    blk = a.ell[bn];
-                    ES = expS[bn * 64 + lane];
-                    EI = expI[bn * 64 + lane];
-                }
-                if (!__any((ESc | EIc) != 0)) continue;
-                const int D = __builtin_amdgcn_readfirstlane(cur.slots);  // same for the whole block
-                if (D <= 0) continue;
-                const size_t off = (size_t)__builtin_amdgcn_readfirstlane(cur.off) * 64;
-                // the block of the seed row has one copy per travel scale (only that row differs)
-                const double* __restrict__ qp =
-                    (b == (a.seed_idx >> 6) && a.qval_seed && !a.seed_long)
-                        ? a.qval_seed + (size_t)ti * a.seed_deg * 64 + lane
-                        : a.qval + off + lane;
-                const int32_t* __restrict__ cp = a.col + off + lane;
-                lane_apportion<DMAX>(ESc, EIc, __any(EIc > 0), D, qp, cp, row, sh_movS, sh_movI, sh_err, t, tm);
-            }
-            // the few rows longer than kLaneSlots: one wave per row with the dense kernel's routine on
-            // the compact row (64 slots, zero padded), scattered through the row's column list
-            for (int o = wave; o < a.n_long; o += kCsrThreads / 64) {
-                const int row = a.long_rows[o];
-                const int32_t ES = __builtin_amdgcn_readfirstlane(expS[row]);
-                const int32_t EI = __builtin_amdgcn_readfirstlane(expI[row]);
-                if ((ES | EI) == 0) continue;
-                const int deg = a.rowptr[row + 1] - a.rowptr[row];
-                const double* __restrict__ qrow =
-                    (row == a.seed_idx && a.qval_seed) ? a.qval_seed + (size_t)ti * a.seed_deg : a.long_q + (size_t)o * 64;
-                const int col = a.long_col[(size_t)o * 64 + lane];
+            // Blocks of 64 rows, then the long rows, are handed out through an LDS counter (rows differ in
+            // cost); the exports and the block record of a wave's next block are fetched while it works on
+            // the current one.
+            const int nitems = nblocks + a.n_long;
+            auto grab = [&]() {
+                int v = 0;
+                if (lane == 0) v = atomicAdd(sh_next, 1);
+                return __builtin_amdgcn_readfirstlane(v);
+            };
+            int item = grab();
+            EllBlock blk = a.ell[item < nblocks ? item : 0];
+            int32_t ES = expS[(item < nblocks ? item : 0) * 64 + lane], EI = expI[(item < nblocks ? item : 0) * 64 + lane];
+            while (item < nitems) {
+                const int next = grab();
+                if (item < nblocks) {
+                    const int b = item;
+                    const int row = b * 64 + lane;
+                    const EllBlock cur = blk;
+                    // rows longer than kLaneSlots are empty in the lane layout and handled as long rows
+                    const bool valid = row < n && !((cur.long_mask >> lane) & 1ull);
+                    const int32_t ESc = valid ? ES : 0, EIc = valid ? EI : 0;
+                    {
+                        const int bn = next < nblocks ? next : b;
+                        blk = a.ell[bn];
+                        ES = expS[bn * 64 + lane];
+                        EI = expI[bn * 64 + lane];
+                    }
+                    const int D = __builtin_amdgcn_readfirstlane(cur.slots);  // same for the whole block
+                    if (__any((ESc | EIc) != 0) && D > 0) {
+                        const size_t off = (size_t)__builtin_amdgcn_readfirstlane(cur.off) * 64;
+                        // the block of the seed row has one copy per travel scale (only that row differs)
+                        const double* __restrict__ qp =
+                            (b == (a.seed_idx >> 6) && a.qval_seed && !a.seed_long)
+                                ? a.qval_seed + (size_t)ti * a.seed_deg * 64 + lane
+                                : a.qval + off + lane;
+                        const int32_t* __restrict__ cp = a.col + off + lane;
+                        lane_apportion<DMAX>(ESc, EIc, __any(EIc > 0), D, qp, cp, row, sh_movS, sh_movI, sh_err, t, tm);
+                    }
+                } else {
+                    // a row longer than kLaneSlots: one wave with the dense kernel's routine on the compact
+                    // row (64 slots, zero padded), scattered through the row's column list
+                    const int o = item - nblocks;
+                    const int row = a.long_rows[o];
+                    const int32_t ESl = __builtin_amdgcn_readfirstlane(expS[row]);
+                    const int32_t EIl = __builtin_amdgcn_readfirstlane(expI[row]);
+                    if ((ESl | EIl) != 0) {
+                        const int deg = a.rowptr[row + 1] - a.rowptr[row];
+                        const double* __restrict__ qrow = (row == a.seed_idx && a.qval_seed)
+                                                              ? a.qval_seed + (size_t)ti * a.seed_deg
+                                                              : a.long_q + (size_t)o * 64;
+                        const int col = a.long_col[(size_t)o * 64 + lane];
 #pragma nounroll
-                for (int comp = 0; comp < 2; ++comp) {
-                    const int32_t E = comp ? EI : ES;
-                    uint32_t acc[1] = {0u};
-                    if (E > 0) apportion_row<1>(E, deg, -1, qrow, acc, lane, nullptr);
-                    if (col >= 0 && col != row && acc[0]) atomicAdd(comp ? &sh_movI[col] : &sh_movS[col], acc[0]);
+                        for (int comp = 0; comp < 2; ++comp) {
+                            const int32_t E = comp ? EIl : ESl;
+                            uint32_t acc[1] = {0u};
+                            if (E > 0) apportion_row<1>(E, deg, -1, qrow, acc, lane, nullptr);
+                            if (col >= 0 && col != row && acc[0]) atomicAdd(comp ? &sh_movI[col] : &sh_movS[col], acc[0]);
+                        }
+                    }
                 }
+                item = next;
             }
         }
         EPI_TM({ const long long k1 = clock64(); tm[5] += k1 - k0; k0 = k1; })
         __syncthreads();
         EPI_TM({ const long long k1 = clock64(); tm[6] += k1 - k0; k0 = k1; })
-
-        // ------------------------------------------------------------------ phase C: apply
-        unsigned long long mass_move = 0ull;
-        for (int cc = tid; cc < n; cc += kCsrThreads) {
-            int c = cc;
-            asm volatile("" : "+v"(c));
-            const int32_t movedS = (int32_t)(sh_movS[c] - (uint32_t)expS[c]);
-            const int32_t movedI = (int32_t)(sh_movI[c] - (uint32_t)expI[c]);
-            const double ns = fmax(0.0, (double)st_s[c] + (double)movedS);
-            const double ni = fmax(0.0, (double)st_i[c] + (double)movedI);
-            const int32_t tc = a.tcur[eoff + c];
-            if (ns > 2147483647.0 || ni > 2147483647.0) record_error(sh_err, EPI_ERR_INT_RANGE, c, tc);
-            const int32_t s3 = (int32_t)ns, i3 = (int32_t)ni;
-            st_s[c] = s3;
-            st_i[c] = i3;
-            a.tcur[eoff + c] = min(tc + 1, a.step_t_max);
-            if (a.arrival[eoff + c] < 0 && i3 >= 10) a.arrival[eoff + c] = t;
-            if (i3 > a.peak[eoff + c]) a.peak[eoff + c] = i3;
-            if (a.flow_s) {
-                a.flow_s[eoff + c] = movedS;
-                a.flow_i[eoff + c] = movedI;
-            }
-            const long long tm = (long long)s3 + i3 + st_r[c] + st_d[c] + st_v[c];
-            mass_move += tm > 0 ? (unsigned long long)tm : 0ull;
-        }
-        if (a.validate) {
-            const unsigned long long wsum = wave_sum_u64(mass_move);
-            if (lane == 0) atomicAdd(&sh_mass[par * 2 + 1], wsum);
-        }
-        // patch c is read here and re-initialised in the next phase A by the same thread: no barrier
-        EPI_TM(__builtin_amdgcn_s_waitcnt(0); { const long long k1 = clock64(); tm[7] += k1 - k0; })
     }
     EPI_TM(if (a.stats && lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&a.stats[48 + i], (unsigned long long)tm[i]);)
     __syncthreads();
