@@ -347,6 +347,39 @@ def test_grid_sparse_matches_oracle(epi, n, deg, nb, nt, steps, eps):
     util.assert_grid_equal(got, want)
 
 
+@pytest.mark.parametrize("deg,lo,hi,seed_idx", [(4.0, 1, 16, 0), (9.0, 17, 24, 0), (15.0, 25, 32, 0), (9.0, 17, 24, 777),
+                                                (15.0, 25, 32, 1150), (26.0, 33, 64, 0)])
+def test_grid_sparse_kernel_variants(epi, deg, lo, hi, seed_idx):
+    """One case per compiled row width of the sparse kernel (16, 24 and 32 slots per lane) and for long rows,
+    with the seed row in the first block and in a later one.  The longest row decides the variant; the
+    graph is regenerated until it falls in the wanted range."""
+    from epidemicsimulator_amd import synth
+    n, steps = 1216, 12
+    for seed in range(500, 540):
+        wl = _sparse_workload(n, deg, 1, 2, steps, seed=seed)
+        rp = wl["conn"][0]
+        lane_max = int(np.max(np.where(np.diff(rp) <= 32, np.diff(rp), 0)))
+        longest = int(np.max(np.diff(rp)))
+        if lo <= (longest if hi > 32 else lane_max) <= hi and (hi > 32 or longest <= 32 or deg >= 15.0):
+            break
+    else:
+        pytest.skip("no graph with the wanted longest row")
+    if hi > 32:  # make the seed row itself one of the long rows
+        seed_idx = int(np.argmax(np.diff(rp)))
+    wl["seed_idx"] = seed_idx
+    base = synth.base_state(steps)
+    got = util.engine_grid(wl, base, True)
+    ta = np.zeros(n); tp = np.zeros(n); ha = np.ones(n, dtype=np.uint8)
+    for c, v in wl["t_arrive"].items():
+        ta[c] = v
+    for c, v in wl["t_peak"].items():
+        tp[c] = v
+    want = O.grid_surface([c.pop for c in wl["countries"]], util.dense_of(wl["conn"], n), seed_idx, util.oracle_state(base),
+                          [util.prof_dict(p) for p in wl["profiles"]], steps, wl["betas"], wl["travel"], ta, ha, tp, ha, True)
+    util.assert_grid_equal(got, want)
+    assert (got["arrival"] < steps).sum() > 2 * 3, "the infection should have left the seed patch"
+
+
 def test_world_sparse_step_given_actions(epi):
     from epidemicsimulator_amd import synth
     n = 1200
