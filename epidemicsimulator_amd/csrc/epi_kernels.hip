@@ -458,50 +458,73 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
         EPI_TM(long long k0 = clock64();)
         if (tid == 0) *sh_next = 0;
         unsigned long long mass_local = 0ull, mass_move = 0ull;
-        for (int cc = tid; cc < n; cc += kCsrThreads) {
+        // The inputs of a thread's next patch are fetched before the current one is worked on: a thread
+        // visits about n / 768 patches per step and would otherwise expose one memory latency for each.
+        struct PatchIn {
+            int32_t s, i, r, d, v, tc, es, ei, arr, pk;
+            uint32_t ms, mi;
+            StepConsts k;
+            int act;
+            double z, cap, sw;
+        };
+        auto fetch = [&](int cc) {
             // the index is made opaque: otherwise one 64-bit address per array is precomputed ahead of the
             // step loop and kept (spilled) for the whole kernel
             int c = cc;
             asm volatile("" : "+v"(c));
-            int32_t s0 = st_s[c], i0 = st_i[c];
-            const int32_t r0 = st_r[c], d0 = st_d[c], v0 = st_v[c];
-            int32_t tc = a.tcur[eoff + c];
-            StepConsts k;
-            int act = 0;
-            double z = 0.0, cap0 = 0.0, sw = 0.0;
-            if (doA) {
-                k.beta0 = a.beta0[(size_t)bi * NP + c];
-                k.gamma = a.cst[CST_GAMMA * NP + c];
-                k.ifr0 = a.cst[CST_IFR0 * NP + c];
-                k.cnoise = a.cst[CST_CNOISE * NP + c];
-                k.eff1 = a.cst[CST_EFF1 * NP + c];
-                k.eff2 = a.cst[CST_EFF2 * NP + c];
-                k.eff3 = a.cst[CST_EFF3 * NP + c];
-                k.surge = a.cst[CST_SURGE * NP + c];
-                k.vax6 = a.cst[CST_VAX6 * NP + c];
-                k.vax7 = a.cst[CST_VAX7 * NP + c];
-                act = a.act_episode ? (int)a.act_episode[eoff + c] : (int)a.actions[(size_t)(t - a.act_t0) * NP + c];
-                act = act < 0 ? 0 : (act > 7 ? 7 : act);
-                z = a.noise_episode ? a.noise_episode[eoff + c] : a.noise[(size_t)(t - a.noise_t0) * NP + c];
-                cap0 = a.cap[eoff + c];
-                sw = (c == a.seed_idx && a.qval_seed) ? a.sumw_seed[ti] : a.sumw[c];
-                // every constant is fetched with the state, in one batch: left alone, the loads of those that only
-                // some actions use sink into the action branches, one exposed memory latency each
-                keep_loaded(k.eff1); keep_loaded(k.eff2); keep_loaded(k.eff3); keep_loaded(k.surge);
-                keep_loaded(k.vax6); keep_loaded(k.vax7); keep_loaded(k.ifr0); keep_loaded(k.cnoise);
+            PatchIn p;
+            p.s = st_s[c]; p.i = st_i[c]; p.r = st_r[c]; p.d = st_d[c]; p.v = st_v[c];
+            p.tc = a.tcur[eoff + c];
+            p.es = p.ei = p.arr = p.pk = 0;
+            p.ms = p.mi = 0u;
+            p.act = 0;
+            p.z = p.cap = p.sw = 0.0;
+            if (doC) {
+                p.ms = sh_movS[c]; p.mi = sh_movI[c];
+                p.es = expS[c]; p.ei = expI[c];
+                p.arr = a.arrival[eoff + c]; p.pk = a.peak[eoff + c];
             }
+            if (doA) {
+                p.k.beta0 = a.beta0[(size_t)bi * NP + c];
+                p.k.gamma = a.cst[CST_GAMMA * NP + c];
+                p.k.ifr0 = a.cst[CST_IFR0 * NP + c];
+                p.k.cnoise = a.cst[CST_CNOISE * NP + c];
+                p.k.eff1 = a.cst[CST_EFF1 * NP + c];
+                p.k.eff2 = a.cst[CST_EFF2 * NP + c];
+                p.k.eff3 = a.cst[CST_EFF3 * NP + c];
+                p.k.surge = a.cst[CST_SURGE * NP + c];
+                p.k.vax6 = a.cst[CST_VAX6 * NP + c];
+                p.k.vax7 = a.cst[CST_VAX7 * NP + c];
+                p.act = a.act_episode ? (int)a.act_episode[eoff + c] : (int)a.actions[(size_t)(t - a.act_t0) * NP + c];
+                p.z = a.noise_episode ? a.noise_episode[eoff + c] : a.noise[(size_t)(t - a.noise_t0) * NP + c];
+                p.cap = a.cap[eoff + c];
+                p.sw = (c == a.seed_idx && a.qval_seed) ? a.sumw_seed[ti] : a.sumw[c];
+            }
+            return p;
+        };
+        PatchIn nx = fetch(tid < n ? tid : 0);
+        for (int cc = tid; cc < n; cc += kCsrThreads) {
+            int c = cc;
+            asm volatile("" : "+v"(c));
+            PatchIn p = nx;
+            nx = fetch(cc + kCsrThreads < n ? cc + kCsrThreads : cc);
+            // every constant is fetched with the state, in one batch: left alone, the loads of those that only
+            // some actions use sink into the action branches, one exposed memory latency each
+            keep_loaded(nx.k.eff1); keep_loaded(nx.k.eff2); keep_loaded(nx.k.eff3); keep_loaded(nx.k.surge);
+            keep_loaded(nx.k.vax6); keep_loaded(nx.k.vax7); keep_loaded(nx.k.ifr0); keep_loaded(nx.k.cnoise);
+            int32_t s0 = p.s, i0 = p.i, tc = p.tc;
+            const int32_t r0 = p.r, d0 = p.d, v0 = p.v;
             if (doC) {  // ---- phase C of step t-1 (WorldToy.scala:128-145)
-                const int32_t movedS = (int32_t)(sh_movS[c] - (uint32_t)expS[c]);
-                const int32_t movedI = (int32_t)(sh_movI[c] - (uint32_t)expI[c]);
-                const int32_t arr = a.arrival[eoff + c], pk = a.peak[eoff + c];
+                const int32_t movedS = (int32_t)(p.ms - (uint32_t)p.es);
+                const int32_t movedI = (int32_t)(p.mi - (uint32_t)p.ei);
                 const double ns = fmax(0.0, (double)s0 + (double)movedS);
                 const double ni = fmax(0.0, (double)i0 + (double)movedI);
                 if (ns > 2147483647.0 || ni > 2147483647.0) record_error(sh_err, EPI_ERR_INT_RANGE, c, tc);
                 s0 = (int32_t)ns;
                 i0 = (int32_t)ni;
                 tc = min(tc + 1, a.step_t_max);
-                if (arr < 0 && i0 >= 10) a.arrival[eoff + c] = t - 1;
-                if (i0 > pk) a.peak[eoff + c] = i0;
+                if (p.arr < 0 && i0 >= 10) a.arrival[eoff + c] = t - 1;
+                if (i0 > p.pk) a.peak[eoff + c] = i0;
                 if (a.flow_s) {
                     a.flow_s[eoff + c] = movedS;
                     a.flow_i[eoff + c] = movedI;
@@ -510,8 +533,10 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 mass_move += tmv > 0 ? (unsigned long long)tmv : 0ull;
             }
             if (doA) {  // ---- phase A of step t (WorldToy.scala:83-104)
+                int act = p.act;
+                act = act < 0 ? 0 : (act > 7 ? 7 : act);
                 const long long tb = (long long)s0 + i0 + r0 + d0 + v0;
-                const LocalOut o = local_step(k, s0, i0, r0, d0, v0, cap0, act, z);
+                const LocalOut o = local_step(p.k, s0, i0, r0, d0, v0, p.cap, act, p.z);
                 const long long ta = (long long)o.s + o.i + o.r + o.d + o.v;
                 if (a.validate && ta != tb) record_error(sh_err, EPI_ERR_LOCAL_MASS, c, tc);
                 if ((o.s | o.i | o.r | o.d | o.v) < 0) record_error(sh_err, EPI_ERR_INT_RANGE, c, tc);
@@ -519,8 +544,8 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 st_s[c] = o.s; st_i[c] = o.i; st_r[c] = o.r; st_d[c] = o.d; st_v[c] = o.v;
                 a.cap[eoff + c] = o.cap;
                 a.tcur[eoff + c] = tc + 1;
-                expS[c] = export_count(max(0, o.s), sw);
-                expI[c] = export_count(max(0, o.i), sw);
+                expS[c] = export_count(max(0, o.s), p.sw);
+                expI[c] = export_count(max(0, o.i), p.sw);
                 sh_movS[c] = 0u;
                 sh_movI[c] = 0u;
                 mass_local += ta > 0 ? (unsigned long long)ta : 0ull;
