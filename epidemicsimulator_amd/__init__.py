@@ -17,7 +17,7 @@ from . import _capi
 from ._capi import (EpiError, IllegalArgumentException, EPI_OK, check, f64, i32, lib, ptr)
 
 __all__ = ["Action", "State", "HyperParams", "TrainConfig", "Geo", "ToyConn", "EpidemicEnv", "WorldToy",
-           "Calibrate", "Validation", "GridEngine", "EpiError", "IllegalArgumentException"]
+           "Calibrate", "Validation", "GridEngine", "Snapshots", "EpiError", "IllegalArgumentException"]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -402,6 +402,8 @@ class WorldToy:
         hyper_params: HyperParams
         s: State
         last_a: int = 0
+        arrival: int = -1     # first step index with I >= 10 since the last reset (Validation.arrivalTime), -1 = not yet
+        peak_i: float = 0.0   # running Validation.peakI
 
     def __init__(self, hp: HyperParams, base: State, seed_idx: int = 0, conn=None,
                  make_env: Callable[[], EpidemicEnv] = lambda: EpidemicEnv(),
@@ -435,6 +437,7 @@ class WorldToy:
         self._h = C.c_void_p(h)
         self._agents = [_AgentStream(hp) for _ in range(n)]
         self._mlp = None
+        self._steps_done = 0
         st0 = self._get_states()
         self.nodes = [WorldToy.Node(i, c.name, c.pop, envs[i], hp, st0[0][i]) for i, c in enumerate(self.countries)]
 
@@ -467,6 +470,17 @@ class WorldToy:
     def reset_to_initial(self) -> None:  # :77
         check(lib().epi_world_reset(self._h))
         self._sync_nodes()
+        self._steps_done = 0
+        for node in self.nodes:
+            node.arrival, node.peak_i = -1, 0.0
+
+    def _track(self, states):
+        """Arrival / peak bookkeeping of instance 0 for the snapshot stream (Validation.scala:15-22)."""
+        for node, s in zip(self.nodes, states):
+            if node.arrival < 0 and s.i >= 10.0:
+                node.arrival = self._steps_done
+            node.peak_i = max(node.peak_i, s.i)
+        self._steps_done += 1
 
     def _sync_nodes(self):
         arr = (_capi.CState * (self.batch * self.n))()
@@ -491,6 +505,7 @@ class WorldToy:
         states = [[State._from_c(out[b * self.n + c]) for c in range(self.n)] for b in range(self.batch)]
         for node, s, act in zip(self.nodes, states[0], a[0]):
             node.s, node.last_a = s, int(act)
+        self._track(states[0])
         return states, r
 
     # numpy image of one State record as the C ABI lays it out (epi_state, 64 bytes)
@@ -557,6 +572,7 @@ class WorldToy:
         states = [State._from_c(out[c]) for c in range(self.n)]
         for node, s, act in zip(self.nodes, states, a[0]):
             node.s, node.last_a = s, int(act)
+        self._track(states)
         return [(nd.name, s, float(rv)) for nd, s, rv in zip(self.nodes, states, r[0])]
 
 
@@ -679,3 +695,48 @@ class Calibrate:
                 for i, b in enumerate(beta_grid) for k, ts in enumerate(travel_scales)]
         bi, bl = grid_argmin(loss)
         return rows, (bl, (rows[bi][0], rows[bi][1]))
+
+    # -- calibration-surface file (the CSV the reference's heatmap script reads: columns beta, travel, loss;
+    #    src/main/scala/resources/plot_histogram.py:12-13).  The reference tree holds no writer for it, so the
+    #    number format is this engine's choice: the shortest decimal that parses back to the same double.
+    @staticmethod
+    def write_surface_csv(path: str, rows: Sequence[Tuple[float, float, float]]) -> None:
+        with open(path, "w", newline="\n") as f:
+            f.write("beta,travel,loss\n")
+            for b, ts, loss in rows:
+                f.write("%s,%s,%s\n" % (repr(float(b)), repr(float(ts)), repr(float(loss))))
+
+    @staticmethod
+    def read_surface_csv(path: str) -> List[Tuple[float, float, float]]:
+        with open(path) as f:
+            head = f.readline().strip()
+            if head != "beta,travel,loss":
+                raise ValueError("%s: not a calibration surface (header %r)" % (path, head))
+            return [tuple(float(x) for x in line.split(",")) for line in f if line.strip()]
+
+
+class Snapshots:
+    """Snapshot stream of the trainer (README.md:14: records (country, t, i, arrival, peakI, loss) under
+    stream_in/snapshots; call sites MutliTrainer.scala:113,125).  The reference tree does not contain the
+    writer itself, so the file layout is this engine's choice: one JSON-lines file per call, one record per
+    country, which a Spark `readStream.schema(...).json(dir)` source picks up as it appears."""
+
+    FIELDS = ("country", "t", "i", "arrival", "peakI", "loss")
+
+    @staticmethod
+    def records(world: "WorldToy", step: int, loss: float) -> List[dict]:
+        return [{"country": nd.name, "t": int(step), "i": float(nd.s.i), "arrival": int(nd.arrival),
+                 "peakI": float(nd.peak_i), "loss": float(loss)} for nd in world.nodes]
+
+    @staticmethod
+    def write_epoch_snapshot(world: "WorldToy", step: int, loss: float, out_dir: str = "stream_in/snapshots") -> str:
+        import json
+        import os
+        os.makedirs(out_dir, exist_ok=True)
+        final = os.path.join(out_dir, "snapshot-%010d.json" % int(step))
+        tmp = final + ".tmp"   # written under another name and renamed: a streaming reader never sees half a file
+        with open(tmp, "w", newline="\n") as f:
+            for rec in Snapshots.records(world, step, loss):
+                f.write(json.dumps(rec, allow_nan=False) + "\n")
+        os.replace(tmp, final)
+        return final

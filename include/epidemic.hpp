@@ -8,7 +8,10 @@
 #pragma once
 #include <array>
 #include <cmath>
+#include <algorithm>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <map>
 #include <memory>
@@ -259,6 +262,8 @@ public:
         HyperParams hyperParams;
         State s;
         int lastA = 0;
+        int arrival = -1;     // first step index with I >= 10 since the last reset (Validation.arrivalTime); -1 = not yet
+        double peakI = 0.0;   // running Validation.peakI
     };
     using Step = std::vector<std::tuple<std::string, State, double>>;
 
@@ -315,6 +320,8 @@ public:
     void resetToInitial() {  // :77
         check(epi_world_reset(h_));
         syncNodes();
+        stepsDone_ = 0;
+        for (auto& nd : nodes) { nd.arrival = -1; nd.peakI = 0.0; }
     }
 
     // WorldToy.stepOne (:83-170) with never-trained agents: epsilon-greedy draws follow the JVM streams;
@@ -388,13 +395,17 @@ private:
         for (size_t c = 0; c < nodes.size(); ++c) {
             nodes[c].s = State::from(out[c]);
             nodes[c].lastA = acts[c];
+            if (nodes[c].arrival < 0 && nodes[c].s.i >= 10.0) nodes[c].arrival = stepsDone_;
+            nodes[c].peakI = std::max(nodes[c].peakI, nodes[c].s.i);
             res.emplace_back(nodes[c].name, nodes[c].s, rew[c]);
         }
+        ++stepsDone_;
         return res;
     }
     HyperParams hp_;
     State base_;
     epi_world* h_ = nullptr;
+    int stepsDone_ = 0;
     std::vector<Stream> streams_;
     std::vector<double> W1_, W2_, W3_;
 };
@@ -444,6 +455,67 @@ inline Surface gridSurface(const HyperParams& hp, const TrainConfig& cfg, const 
     if (bestLoss < 1.7976931348623157e308) bestPair = {std::get<0>(rows[bestIdx]), std::get<1>(rows[bestIdx])};
     return {rows, {bestLoss, bestPair}};
 }
+
+// Shortest decimal text that parses back to the same double.
+inline std::string doubleText(double x) {
+    char buf[40];
+    for (int prec = 1; prec <= 17; ++prec) {
+        std::snprintf(buf, sizeof buf, "%.*g", prec, x);
+        if (std::strtod(buf, nullptr) == x) break;
+    }
+    return buf;
+}
+
+// The CSV the reference's heatmap script reads (columns beta, travel, loss;
+// src/main/scala/resources/plot_histogram.py:12-13).  The reference tree holds no writer for it: the number
+// format is this engine's choice, the shortest decimal that parses back to the same double.
+inline void writeSurfaceCsv(const std::string& path, const std::vector<Row>& rows) {
+    std::FILE* f = std::fopen(path.c_str(), "w");
+    if (!f) throw std::runtime_error("cannot write " + path);
+    std::fputs("beta,travel,loss\n", f);
+    for (const Row& r : rows)
+        std::fprintf(f, "%s,%s,%s\n", doubleText(std::get<0>(r)).c_str(), doubleText(std::get<1>(r)).c_str(),
+                     doubleText(std::get<2>(r)).c_str());
+    std::fclose(f);
+}
+
+inline std::vector<Row> readSurfaceCsv(const std::string& path) {
+    std::FILE* f = std::fopen(path.c_str(), "r");
+    if (!f) throw std::runtime_error("cannot read " + path);
+    char line[256];
+    std::vector<Row> rows;
+    if (!std::fgets(line, sizeof line, f) || std::string(line).rfind("beta,travel,loss", 0) != 0) {
+        std::fclose(f);
+        throw std::runtime_error(path + ": not a calibration surface");
+    }
+    double b, ts, l;
+    while (std::fgets(line, sizeof line, f))
+        if (std::sscanf(line, "%lf,%lf,%lf", &b, &ts, &l) == 3) rows.emplace_back(b, ts, l);
+    std::fclose(f);
+    return rows;
+}
 }  // namespace Calibrate
+
+// ---- snapshot stream of the trainer ----------------------------------------------------------------
+// README.md:14: records (country, t, i, arrival, peakI, loss) under stream_in/snapshots; call sites
+// MutliTrainer.scala:113,125.  The reference tree does not contain the writer itself, so the file layout is
+// this engine's choice: one JSON-lines file per call, one record per country, written under a temporary name
+// and renamed so that a streaming reader never sees half a file.  The directory must exist.
+namespace Snapshots {
+inline std::string writeEpochSnapshot(const WorldToy& world, int step, double loss, const std::string& outDir = "stream_in/snapshots") {
+    char name[64];
+    std::snprintf(name, sizeof name, "/snapshot-%010d.json", step);
+    const std::string fin = outDir + name, tmp = fin + ".tmp";
+    std::FILE* f = std::fopen(tmp.c_str(), "w");
+    if (!f) throw std::runtime_error("cannot write " + tmp);
+    for (const auto& nd : world.nodes)
+        std::fprintf(f, "{\"country\": \"%s\", \"t\": %d, \"i\": %s, \"arrival\": %d, \"peakI\": %s, \"loss\": %s}\n", nd.name.c_str(),
+                     step, Calibrate::doubleText(nd.s.i).c_str(), nd.arrival, Calibrate::doubleText(nd.peakI).c_str(),
+                     Calibrate::doubleText(loss).c_str());
+    std::fclose(f);
+    if (std::rename(tmp.c_str(), fin.c_str()) != 0) throw std::runtime_error("cannot rename " + tmp);
+    return fin;
+}
+}  // namespace Snapshots
 
 }  // namespace epidemic

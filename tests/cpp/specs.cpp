@@ -143,6 +143,49 @@ static void heterogeneitySpec() {
     EXPECT(sCn1.s + sCn1.i + sCn1.r + sCn1.d + sCn1.v == 1001000.0);
 }
 
+// Wire formats either side of the path: the calibration-surface CSV the reference's heatmap script reads
+// (plot_histogram.py:12-13) and the snapshot records of README.md:14.  No reference spec exists for them.
+static void wireFormats() {
+    HyperParams hp;
+    TrainConfig cfg;
+    cfg.epochs = 1;
+    cfg.stepsPerEpoch = 40;
+    State base{1000000, 0, 0, 0, 0, 10000, 0, 40, 3};
+    Calibrate::Targets targets;
+    targets.tArrive = {{"Japan", 12.0}, {"India", 9.0}};
+    targets.peakI = {{"USA", 400000.0}};
+    auto res = Calibrate::gridSurface(hp, cfg, base, 0, targets, {0.24, 0.26, 0.3}, {0.8, 1.0});
+    char dir[] = "/tmp/epi_specs_XXXXXX";
+    EXPECT(mkdtemp(dir) != nullptr);
+    const std::string csv = std::string(dir) + "/calib_surface.csv";
+    Calibrate::writeSurfaceCsv(csv, res.first);
+    EXPECT(Calibrate::readSurfaceCsv(csv) == res.first);  // exact round trip of every double
+    std::FILE* f = std::fopen(csv.c_str(), "r");
+    char head[64] = {0};
+    EXPECT(f && std::fgets(head, sizeof head, f) && std::string(head) == "beta,travel,loss\n");
+    if (f) std::fclose(f);
+    WorldToy w(hp, State{0, 0, 0, 0, 0, 10000, 0, 120, 42}, 0, ToyConn::W(), [] { return std::make_shared<EpidemicEnv>(); }, nullptr, true);
+    std::vector<double> usa;
+    for (int k = 0; k < 25; ++k) {
+        auto step = w.stepOne(120);
+        usa.push_back(std::get<1>(step[0]).i);
+    }
+    EXPECT(w.nodes[0].arrival == Validation::arrivalTime(usa) && w.nodes[0].peakI == Validation::peakI(usa));
+    const std::string snap = Snapshots::writeEpochSnapshot(w, 25, 0.125, dir);
+    f = std::fopen(snap.c_str(), "r");
+    EXPECT(f != nullptr);
+    int lines = 0;
+    char line[512];
+    while (f && std::fgets(line, sizeof line, f)) {
+        ++lines;
+        EXPECT(std::string(line).find("\"country\": \"") != std::string::npos && std::string(line).find("\"loss\": 0.125}") != std::string::npos);
+    }
+    if (f) std::fclose(f);
+    EXPECT(lines == 6);
+    w.resetToInitial();
+    EXPECT(w.nodes[0].arrival == -1 && w.nodes[0].peakI == 0.0);
+}
+
 int main() {
     if (epi_device_count() < 1) {
         std::printf("no HIP device: the specs need the GPU engine\n");
@@ -152,7 +195,7 @@ int main() {
         const char* name;
         void (*fn)();
     } specs[] = {{"ValidationSpec", validationSpec}, {"MobilitySpec", mobilitySpec}, {"CalibrationSpec", calibrationSpec},
-                 {"EvalDeterminismSpec", evalDeterminismSpec}, {"HeterogeneitySpec", heterogeneitySpec}};
+                 {"EvalDeterminismSpec", evalDeterminismSpec}, {"HeterogeneitySpec", heterogeneitySpec}, {"WireFormats", wireFormats}};
     for (auto& s : specs) {
         const int before = failures;
         try {

@@ -143,3 +143,28 @@ def test_synthetic_inputs_are_deterministic(epi):
     for i in range(300):
         c = col[rp[i]:rp[i + 1]]
         assert (np.diff(c) > 0).all() and i not in c
+
+
+def test_surface_csv_is_what_the_heatmap_script_reads(epi, tmp_path):
+    """calib_surface.csv: columns beta, travel, loss, pivoted exactly as the reference's plot script does
+    (src/main/scala/resources/plot_histogram.py:12-13).  Doubles survive the file bit for bit."""
+    import pandas as pd
+    betas = [k / 100.0 for k in range(24, 28)]
+    travel = [k / 10.0 for k in range(5, 10)]
+    rng = np.random.default_rng(4)
+    rows = [(b, ts, float(rng.random() * 10.0 ** int(rng.integers(-8, 8)))) for b in betas for ts in travel]
+    path = tmp_path / "calib_surface.csv"
+    epi.Calibrate.write_surface_csv(str(path), rows)
+    assert open(path).readline() == "beta,travel,loss\n"
+    assert epi.Calibrate.read_surface_csv(str(path)) == rows
+    df = pd.read_csv(path)
+    pivot = df.pivot(index="beta", columns="travel", values="loss")
+    assert pivot.shape == (4, 5)
+    assert list(pivot.index) == betas and list(pivot.columns) == travel
+    for i, b in enumerate(betas):
+        for k, ts in enumerate(travel):
+            # pandas' default float parser drops digits past the 15th or so; the file itself is exact (above)
+            assert abs(pivot.loc[b, ts] - rows[i * 5 + k][2]) <= 1e-12 * abs(rows[i * 5 + k][2])
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.csv").write_text("a,b\n1,2\n")
+        epi.Calibrate.read_surface_csv(str(tmp_path / "bad.csv"))

@@ -530,3 +530,28 @@ def test_bad_inputs_are_rejected(epi):
     w = epi.WorldToy(epi.HyperParams(), epi.State(0, 0, 0, 0, 0, 10_000, 0, 10, 1))
     with pytest.raises(epi.EpiError):
         w.restore_states([epi.State(1.5, 0, 0, 0, 0, 1.0, 0, 10, 1)] * 6)   # non-integer compartment
+
+
+# ---------------------------------------------------------------- wire formats either side of the path
+def test_snapshot_stream_records(epi, tmp_path):
+    """Snapshot records (country, t, i, arrival, peakI, loss) of README.md:14 written as JSON lines; arrival and
+    peak follow Validation.arrivalTime / peakI over the steps since the last reset."""
+    import json
+    hp = epi.HyperParams()
+    w = epi.WorldToy(hp, epi.State(0, 0, 0, 0, 0, 10_000, 0, 120, 42), 0, epi.ToyConn.W, validate=True)
+    series = {nd.name: [] for nd in w.nodes}
+    for k in range(30):
+        for name, s, _ in w.step_one(120):
+            series[name].append(s.i)
+    path = epi.Snapshots.write_epoch_snapshot(w, 30, 0.5, str(tmp_path / "stream_in" / "snapshots"))
+    recs = [json.loads(line) for line in open(path)]
+    assert [r["country"] for r in recs] == [c.name for c in epi.ToyConn.C]
+    for r in recs:
+        assert tuple(r.keys()) == epi.Snapshots.FIELDS
+        want_arr = epi.Validation.arrival_time(series[r["country"]])
+        assert r["arrival"] == (want_arr if want_arr < 30 else -1)
+        assert r["peakI"] == epi.Validation.peak_i(series[r["country"]])
+        assert r["i"] == series[r["country"]][-1] and r["t"] == 30 and r["loss"] == 0.5
+    assert not [f for f in (tmp_path / "stream_in" / "snapshots").iterdir() if f.name.endswith(".tmp")]
+    w.reset_to_initial()
+    assert all(nd.arrival == -1 and nd.peak_i == 0.0 for nd in w.nodes)
