@@ -7,6 +7,7 @@ set -e
 W=${1:-c3}; TAG=${2:-r1}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 P=$R/gpurun_out/${TAG}_$W
+rm -rf $P
 mkdir -p $P
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 python3 $R/bench.py --workload $W --steps 3 --warmup 1 > $P/bench.json 2> $P/bench.err

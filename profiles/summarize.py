@@ -15,10 +15,15 @@ import shutil
 import sys
 
 
+def newest(files):
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 def counters(path, kernel_sub):
     agg = collections.defaultdict(float)
     launches = collections.Counter()
-    for f in glob.glob(os.path.join(path, "*", "*_counter_collection.csv")):
+    # gpurun merges results into an existing directory: only the newest run of each pass counts
+    for f in newest(glob.glob(os.path.join(path, "*", "*_counter_collection.csv"))):
         for r in csv.DictReader(open(f)):
             if kernel_sub in r["Kernel_Name"]:
                 agg[r["Counter_Name"]] += float(r["Counter_Value"])
@@ -30,7 +35,7 @@ def main():
     src, out = sys.argv[1], sys.argv[2]
     bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
     kernel_sub = "episode_csr_kernel" if "CSR" in bench["config"]["workload"] else "episode_dense_kernel"
-    stats_csv = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    stats_csv = newest(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")))[0]
     shutil.copy(stats_csv, out + "_kernel_stats.csv")
     kstats = [r for r in csv.DictReader(open(stats_csv)) if kernel_sub in r["Name"]][0]
     c = {}
