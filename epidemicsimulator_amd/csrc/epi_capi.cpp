@@ -190,9 +190,11 @@ struct GraphTables {
     // sparse mode (n > kMaxDenseN): CSR arrays on the device, raw weights on the host
     bool sparse = false;
     int max_deg = 0, lane_deg = 0;
-    DevBuf d_rowptr, d_col, d_qval, d_ell, d_long_rows, d_long_q, d_long_col;
+    DevBuf d_rowptr, d_col, d_qval, d_ell, d_ell_rows, d_ell_pos, d_long_rows, d_long_q, d_long_col;
     std::vector<int32_t> h_long_rows;     // rows longer than kLaneSlots
     std::vector<int32_t> h_slots, h_off;  // ELL block tables
+    std::vector<int32_t> h_pos;           // row -> position in the lane layout (block * 64 + lane), -1 for long rows
+    int n_blocks = 0;
     std::vector<int32_t> h_rowptr, h_col;
     std::vector<double> h_val;
     std::vector<double> h_ell_q;          // host copy of the ELL weights (seed-block variants are cut from it)
@@ -261,20 +263,34 @@ struct GraphTables {
             if (pop_[c] < 0) return fail(EPI_ERR_BAD_ARGUMENT, "pop[%d] = %d is negative", c, pop_[c]);
             hp[c] = pop_[c];
         }
-        // slot-major blocks of 64 rows: one lane per row reads its k-th weight with a coalesced load
-        const int nblocks = (n + 63) / 64;
-        h_slots.assign((size_t)nblocks, 0);
-        h_off.assign((size_t)nblocks, 0);
-        int total_slots = 0;
+        // Slot-major blocks of 64 rows: one lane per row reads its k-th weight with a coalesced load.  The rows
+        // a lane can hold are sorted by length, longest first, before they are cut into blocks: a block then
+        // stores (and the kernel reads and sorts) about as many slots as its rows really have, and the work
+        // queue of the kernel hands out the expensive blocks first.
         h_long_rows.clear();
-        for (int i = 0; i < n; ++i)
+        std::vector<int32_t> order;
+        for (int i = 0; i < n; ++i) {
             if (h_rowptr[i + 1] - h_rowptr[i] > kLaneSlots) h_long_rows.push_back(i);
+            else order.push_back(i);
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+            return h_rowptr[x + 1] - h_rowptr[x] > h_rowptr[y + 1] - h_rowptr[y];
+        });
+        const int nblocks = ((int)order.size() + 63) / 64;
+        n_blocks = nblocks;
+        h_slots.assign((size_t)(nblocks > 0 ? nblocks : 1), 0);
+        h_off.assign((size_t)(nblocks > 0 ? nblocks : 1), 0);
+        h_pos.assign((size_t)n, -1);
+        std::vector<int32_t> rows((size_t)(nblocks > 0 ? nblocks : 1) * 64, -1);
+        int total_slots = 0;
         lane_deg = 0;
         for (int b = 0; b < nblocks; ++b) {
             int dmax = 0;
-            for (int i = b * 64; i < std::min(n, b * 64 + 64); ++i) {
-                const int deg = h_rowptr[i + 1] - h_rowptr[i];
-                if (deg <= kLaneSlots) dmax = std::max(dmax, deg);
+            for (int l = 0; l < 64 && b * 64 + l < (int)order.size(); ++l) {
+                const int i = order[(size_t)b * 64 + l];
+                rows[(size_t)b * 64 + l] = i;
+                h_pos[i] = b * 64 + l;
+                dmax = std::max(dmax, h_rowptr[i + 1] - h_rowptr[i]);
             }
             lane_deg = std::max(lane_deg, dmax);
             h_slots[b] = dmax;
@@ -283,9 +299,8 @@ struct GraphTables {
         }
         std::vector<double> eq((size_t)(total_slots > 0 ? total_slots : 1) * 64, 0.0);
         std::vector<int32_t> ec((size_t)(total_slots > 0 ? total_slots : 1) * 64, -1);
-        for (int i = 0; i < n; ++i) {
-            const int b = i / 64, l = i % 64, rs = h_rowptr[i], deg = h_rowptr[i + 1] - rs;
-            if (deg > kLaneSlots) continue;  // long rows stay empty in the lane layout
+        for (size_t p = 0; p < order.size(); ++p) {
+            const int i = order[p], b = (int)(p / 64), l = (int)(p % 64), rs = h_rowptr[i], deg = h_rowptr[i + 1] - rs;
             for (int k = 0; k < deg; ++k) {
                 eq[((size_t)h_off[b] + k) * 64 + l] = hq[rs + k];
                 ec[((size_t)h_off[b] + k) * 64 + l] = h_col[rs + k];
@@ -303,14 +318,16 @@ struct GraphTables {
         HIP_TRY(d_long_q.upload(lq));
         HIP_TRY(d_long_col.upload(lc));
         HIP_TRY(d_rowptr.upload(h_rowptr));
-        std::vector<EllBlock> hb((size_t)nblocks);
-        for (int b = 0; b < nblocks; ++b) {
+        std::vector<EllBlock> hb(h_slots.size());
+        for (size_t b = 0; b < hb.size(); ++b) {
             hb[b].slots = h_slots[b];
             hb[b].off = h_off[b];
-            hb[b].long_mask = 0ull;
         }
-        for (int i : h_long_rows) hb[i / 64].long_mask |= 1ull << (i % 64);
         HIP_TRY(d_ell.upload(hb));
+        HIP_TRY(d_ell_rows.upload(rows));
+        std::vector<int32_t> pos_pad((size_t)npad, -1);
+        std::copy(h_pos.begin(), h_pos.end(), pos_pad.begin());
+        HIP_TRY(d_ell_pos.upload(pos_pad));
         HIP_TRY(d_col.upload(ec));
         HIP_TRY(d_qval.upload(eq));
         h_ell_q.swap(eq);
@@ -324,7 +341,9 @@ struct GraphTables {
         if (sparse) {
             ea.q = nullptr; ea.qtop = nullptr;
             ea.rowptr = d_rowptr.as<int32_t>(); ea.col = d_col.as<int32_t>(); ea.qval = d_qval.as<double>();
-            ea.ell = d_ell.as<EllBlock>();
+            ea.ell = d_ell.as<EllBlock>(); ea.ell_rows = d_ell_rows.as<int32_t>(); ea.ell_pos = d_ell_pos.as<int32_t>();
+            ea.n_blocks = n_blocks;
+            ea.seed_block = -1;
             ea.max_deg = lane_deg;
             ea.n_long = (int)h_long_rows.size();
             ea.long_rows = d_long_rows.as<int32_t>(); ea.long_q = d_long_q.as<double>(); ea.long_col = d_long_col.as<int32_t>();
@@ -375,7 +394,7 @@ struct EpisodeBuffers {
         HIP_TRY(peak.ensure(cells * sizeof(int32_t)));
         HIP_TRY(err.ensure((size_t)count_ * 4 * sizeof(int32_t)));
         HIP_TRY(act_ep.ensure(cells));
-        if (sparse) HIP_TRY(exports.ensure(cells * 2 * sizeof(int32_t)));
+        if (sparse) HIP_TRY(exports.ensure(cells * 4 * sizeof(int32_t)));
         count = count_;
         npad = npad_;
         return EPI_OK;
@@ -458,7 +477,7 @@ int32_t assert_initial(const epi_state& b) {
 // ================================================================================================
 struct epi_grid {
     int device = 0;
-    int n = 0, npad = 0, steps = 0, n_beta = 0, n_travel = 0, seed_idx = 0, seed_deg = 0, seed_long = 0;
+    int n = 0, npad = 0, steps = 0, n_beta = 0, n_travel = 0, seed_idx = 0, seed_deg = 0, seed_long = 0, seed_block = -1;
     epi_state base{};
     GraphTables graph;
     DevBuf qseed, sumw_seed, qtop_seed, beta0, cst, actions, noise;
@@ -702,7 +721,9 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
         // a long seed row is read by one wave as 64 padded slots; otherwise the whole 64-row block of the
         // seed row is copied once per travel scale (kLaneSlots slots each) with that one row replaced
         const int slots = seed_long ? 64 : kLaneSlots;
-        const int sb = d->seed_idx / 64, sl = d->seed_idx % 64;
+        const int spos = G->graph.h_pos[d->seed_idx];
+        const int sb = seed_long ? 0 : spos / 64, sl = seed_long ? 0 : spos % 64;
+        G->seed_block = seed_long ? -1 : sb;
         G->seed_long = seed_long ? 1 : 0;
         std::vector<double> hq((size_t)nt * slots * (seed_long ? 1 : 64), 0.0), hs((size_t)nt, 0.0), row((size_t)(deg > 0 ? deg : 1));
         std::vector<double> qrow((size_t)64, 0.0);
@@ -970,6 +991,7 @@ EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, doub
     ea.sumw_seed = g->sumw_seed.as<double>();
     if (g->graph.sparse) {
         ea.qval_seed = g->qseed.as<double>(); ea.seed_deg = g->seed_deg; ea.seed_long = g->seed_long;
+        ea.seed_block = g->seed_block;
         ea.exports = g->work.exports.as<int32_t>();
     } else {
         ea.qseed = g->qseed.as<double>(); ea.qtop_seed = g->qtop_seed.as<double>();

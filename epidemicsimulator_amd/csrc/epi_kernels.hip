@@ -437,6 +437,8 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
     int32_t* __restrict__ st_v = a.st + 4 * plane + eoff;
     int32_t* __restrict__ expS = a.exports + 0 * plane + eoff;
     int32_t* __restrict__ expI = a.exports + 1 * plane + eoff;
+    int32_t* __restrict__ expPS = a.exports + 2 * plane + eoff;  // the same two, indexed by lane-layout position
+    int32_t* __restrict__ expPI = a.exports + 3 * plane + eoff;
 
     if (tid == 0) {
         sh_mass[0] = sh_mass[1] = sh_mass[2] = sh_mass[3] = 0ull;
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
     __syncthreads();
 
     int* sh_next = &sh_err[3];  // work queue of the mobility phase: next block or long row to hand out
-    const int nblocks = (n + 63) >> 6;
+    const int nblocks = a.n_blocks;
     EPI_TM(long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};)  // per-wave cycle counts by phase
 #ifndef EPI_CSR_TIMERS
     long long* tm = nullptr;
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
         // The inputs of a thread's next patch are fetched before the current one is worked on: a thread
         // visits about n / 768 patches per step and would otherwise expose one memory latency for each.
         struct PatchIn {
-            int32_t s, i, r, d, v, tc, es, ei, arr, pk;
+            int32_t s, i, r, d, v, tc, es, ei, arr, pk, pos;
             uint32_t ms, mi;
             StepConsts k;
             int act;
@@ -476,6 +478,7 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
             p.s = st_s[c]; p.i = st_i[c]; p.r = st_r[c]; p.d = st_d[c]; p.v = st_v[c];
             p.tc = a.tcur[eoff + c];
             p.es = p.ei = p.arr = p.pk = 0;
+            p.pos = -1;
             p.ms = p.mi = 0u;
             p.act = 0;
             p.z = p.cap = p.sw = 0.0;
@@ -499,6 +502,7 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 p.z = a.noise_episode ? a.noise_episode[eoff + c] : a.noise[(size_t)(t - a.noise_t0) * NP + c];
                 p.cap = a.cap[eoff + c];
                 p.sw = (c == a.seed_idx && a.qval_seed) ? a.sumw_seed[ti] : a.sumw[c];
+                p.pos = a.ell_pos[c];
             }
             return p;
         };
@@ -544,8 +548,13 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 st_s[c] = o.s; st_i[c] = o.i; st_r[c] = o.r; st_d[c] = o.d; st_v[c] = o.v;
                 a.cap[eoff + c] = o.cap;
                 a.tcur[eoff + c] = tc + 1;
-                expS[c] = export_count(max(0, o.s), p.sw);
-                expI[c] = export_count(max(0, o.i), p.sw);
+                const int32_t eS = export_count(max(0, o.s), p.sw), eI = export_count(max(0, o.i), p.sw);
+                expS[c] = eS;
+                expI[c] = eI;
+                if (p.pos >= 0) {  // second copy where the mobility phase reads it with coalesced loads
+                    expPS[p.pos] = eS;
+                    expPI[p.pos] = eI;
+                }
                 sh_movS[c] = 0u;
                 sh_movI[c] = 0u;
                 mass_local += ta > 0 ? (unsigned long long)ta : 0ull;
@@ -589,33 +598,40 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 return __builtin_amdgcn_readfirstlane(v);
             };
             int item = grab();
-            EllBlock blk = a.ell[item < nblocks ? item : 0];
-            int32_t ES = expS[(item < nblocks ? item : 0) * 64 + lane], EI = expI[(item < nblocks ? item : 0) * 64 + lane];
+            const int b0 = item < nblocks ? item : 0;
+            EllBlock blk = a.ell[b0];
+            int row_n = a.ell_rows[b0 * 64 + lane];
+            int32_t ES = expPS[b0 * 64 + lane], EI = expPI[b0 * 64 + lane];
             while (item < nitems) {
                 const int next = grab();
                 if (item < nblocks) {
                     const int b = item;
-                    const int row = b * 64 + lane;
                     const EllBlock cur = blk;
-                    // rows longer than kLaneSlots are empty in the lane layout and handled as long rows
-                    const bool valid = row < n && !((cur.long_mask >> lane) & 1ull);
-                    const int32_t ESc = valid ? ES : 0, EIc = valid ? EI : 0;
+                    const int row = row_n;
+                    const int32_t ESc = row >= 0 ? ES : 0, EIc = row >= 0 ? EI : 0;
                     {
                         const int bn = next < nblocks ? next : b;
                         blk = a.ell[bn];
-                        ES = expS[bn * 64 + lane];
-                        EI = expI[bn * 64 + lane];
+                        row_n = a.ell_rows[bn * 64 + lane];
+                        ES = expPS[bn * 64 + lane];
+                        EI = expPI[bn * 64 + lane];
                     }
                     const int D = __builtin_amdgcn_readfirstlane(cur.slots);  // same for the whole block
                     if (__any((ESc | EIc) != 0) && D > 0) {
                         const size_t off = (size_t)__builtin_amdgcn_readfirstlane(cur.off) * 64;
                         // the block of the seed row has one copy per travel scale (only that row differs)
-                        const double* __restrict__ qp =
-                            (b == (a.seed_idx >> 6) && a.qval_seed && !a.seed_long)
-                                ? a.qval_seed + (size_t)ti * a.seed_deg * 64 + lane
-                                : a.qval + off + lane;
+                        const double* __restrict__ qp = (b == a.seed_block && a.qval_seed)
+                                                            ? a.qval_seed + (size_t)ti * a.seed_deg * 64 + lane
+                                                            : a.qval + off + lane;
                         const int32_t* __restrict__ cp = a.col + off + lane;
-                        lane_apportion<DMAX>(ESc, EIc, __any(EIc > 0), D, qp, cp, row, sh_movS, sh_movI, sh_err, t, tm);
+                        const bool anyI = __any(EIc > 0);
+                        // blocks are sorted by row length: the routine that fits the block's longest row
+                        if (DMAX >= 32 && D > 24)
+                            lane_apportion<(DMAX >= 32 ? 32 : DMAX)>(ESc, EIc, anyI, D, qp, cp, row, sh_movS, sh_movI, sh_err, t, tm);
+                        else if (DMAX >= 24 && D > 16)
+                            lane_apportion<(DMAX >= 24 ? 24 : DMAX)>(ESc, EIc, anyI, D, qp, cp, row, sh_movS, sh_movI, sh_err, t, tm);
+                        else
+                            lane_apportion<16>(ESc, EIc, anyI, D, qp, cp, row, sh_movS, sh_movI, sh_err, t, tm);
                     }
                 } else {
                     // a row longer than kLaneSlots: one wave with the dense kernel's routine on the compact
@@ -626,7 +642,7 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                     const int32_t EIl = __builtin_amdgcn_readfirstlane(expI[row]);
                     if ((ESl | EIl) != 0) {
                         const int deg = a.rowptr[row + 1] - a.rowptr[row];
-                        const double* __restrict__ qrow = (row == a.seed_idx && a.qval_seed)
+                        const double* __restrict__ qrow = (row == a.seed_idx && a.qval_seed && a.seed_long)
                                                               ? a.qval_seed + (size_t)ti * a.seed_deg
                                                               : a.long_q + (size_t)o * 64;
                         const int col = a.long_col[(size_t)o * 64 + lane];

@@ -21,11 +21,10 @@ enum { CST_GAMMA = 0, CST_IFR0, CST_CNOISE, CST_EFF1, CST_EFF2, CST_EFF3, CST_SU
 
 // One launch of the fused dense episode kernel: steps [t_begin, t_end) of `count` episodes, one
 // workgroup per episode, npad threads (one per padded country, one wave per 64).
-// One block of 64 consecutive rows of a sparse graph in the slot-major layout.
+// One block of 64 rows of a sparse graph in the slot-major layout.
 struct EllBlock {
-    int32_t slots;                 // longest row of the block that is kept in the lane layout
-    int32_t off;                   // first slot of the block in col / qval (in units of 64 entries)
-    unsigned long long long_mask;  // bit l set: row 64*b + l is longer than kLaneSlots and handled as a long row
+    int32_t slots;  // longest row of the block
+    int32_t off;    // first slot of the block in col / qval (in units of 64 entries)
 };
 
 struct EpisodeArgs {
@@ -39,10 +38,15 @@ struct EpisodeArgs {
     const double* sumw;      // [npad]     max(0, sum_j wRow_j)  (WorldToy.scala:114)
     const double* qseed;     // [n_travel][npad] seed-row variants (ToyConn.scaleRow per travel scale)
     const double* sumw_seed; // [n_travel]
-    // sparse graphs (rowptr != NULL): rows in blocks of 64, slot-major (ELL) inside a block: slot k of
-    // row 64*b + l is element (ell[b].off + k) * 64 + l of col / qval
+    // sparse graphs (rowptr != NULL): the rows of at most kLaneSlots weights, sorted by length (longest
+    // first), in blocks of 64, slot-major (ELL) inside a block: slot k of row ell_rows[64*b + l] is element
+    // (ell[b].off + k) * 64 + l of col / qval
     const int32_t* rowptr;    // [n+1] (marks sparse mode; row lengths)
-    const EllBlock* ell;      // [ceil(n/64)]
+    const EllBlock* ell;      // [n_blocks]
+    const int32_t* ell_rows;  // [n_blocks][64] row of each lane, -1 = no row
+    const int32_t* ell_pos;   // [npad] inverse: position 64*b + l of a row in the lane layout, -1 = long row
+    int n_blocks;
+    int seed_block;           // block that holds the seed row, -1 if it is a long row (or there are no variants)
     const int32_t* col;       // ELL columns, ascending inside a row, -1 = padding; every block occupies a whole
                               // number of slot groups (kSlotGroup), the extra slots holding weight 0
     const double* qval;       // ELL normalised weights w_ij / sumW_i (a stored diagonal entry holds 0)
@@ -54,7 +58,8 @@ struct EpisodeArgs {
     const int32_t* long_rows; // [n_long]
     const double* long_q;     // [n_long][64]
     const int32_t* long_col;  // [n_long][64], -1 = padding
-    int32_t* exports;        // [2][count][npad] exportS / exportI scratch of the sparse kernel
+    int32_t* exports;        // [4][count][npad] scratch of the sparse kernel: exportS / exportI by patch, then the
+                             // same two by position in the lane layout
     const double* qtop;      // [n][kTopWeights] each row's largest normalised weights, descending (or NULL)
     const double* qtop_seed; // [n_travel][kTopWeights]
     const double* beta0;     // [n_beta][npad] or [1][npad]
