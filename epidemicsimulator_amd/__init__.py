@@ -202,6 +202,36 @@ class ToyConn:
         return W
 
     @staticmethod
+    def gravity_matrix_device(countries, a=0.2, b=1.0, g=1.2, k=1e-6, cap_row=0.12, device: int = 0) -> np.ndarray:
+        """ToyConn.scala:22-47 computed on the GPU (for large synthetic graphs).  Entries may differ from
+        gravity_matrix() in the last place: the device library's pow/sin/cos/atan2 are not the host's."""
+        n = len(countries)
+        pop = i32([c.pop for c in countries]); lat = f64([c.lat for c in countries]); lon = f64([c.lon for c in countries])
+        fl = None
+        names = [c.name for c in countries]
+        pairs = [(names.index(x), names.index(y), v) for (x, y), v in ToyConn.flight_mul.items() if x in names and y in names]
+        if pairs:
+            fl = np.ones((n, n))
+            for x, y, v in pairs:
+                fl[x, y] = v
+        W = np.zeros((n, n))
+        check(lib().epi_gravity_matrix(n, ptr(pop, C.c_int32), ptr(lat, C.c_double), ptr(lon, C.c_double),
+                                       ptr(fl, C.c_double) if fl is not None else None, a, b, g, k, cap_row,
+                                       ptr(W, C.c_double), device))
+        return W
+
+    @staticmethod
+    def to_csr(W, threshold: float = 0.0):
+        """Dense -> (rowptr, col, val) keeping the off-diagonal entries above `threshold`, columns ascending."""
+        W = np.asarray(W, dtype=np.float64)
+        keep = W > threshold
+        np.fill_diagonal(keep, False)
+        rowptr = np.zeros(W.shape[0] + 1, dtype=np.int32)
+        rowptr[1:] = np.cumsum(keep.sum(axis=1))
+        rows, cols = np.nonzero(keep)
+        return rowptr, cols.astype(np.int32), W[rows, cols]
+
+    @staticmethod
     def scale_edge(W, src: int, dst: int, factor: float) -> np.ndarray:  # ToyConn.scala:51-55
         A = np.array(W, dtype=np.float64, copy=True)
         A[src, dst] *= factor

@@ -76,7 +76,7 @@ class WorldDesc(C.Structure):
 # Every symbol include/epi.h declares; tests check that the library exports all of them.
 EXPORTED_SYMBOLS = [
     "epi_version", "epi_last_error", "epi_device_count", "epi_alloc_int", "epi_alloc_int_batch",
-    "epi_env_step_batch", "epi_scale_row", "epi_java_gaussians", "epi_agent_actions", "epi_mlp_init",
+    "epi_env_step_batch", "epi_scale_row", "epi_gravity_matrix", "epi_java_gaussians", "epi_agent_actions", "epi_mlp_init",
     "epi_mlp_greedy_batch", "epi_grid_create", "epi_grid_run", "epi_grid_status", "epi_grid_destroy",
     "epi_grid_argmin", "epi_calibrate_grid", "epi_grid_set_timing", "epi_grid_kernel_time", "epi_world_create", "epi_world_step", "epi_world_step_greedy",
     "epi_world_set_mlp", "epi_world_get_states", "epi_world_set_states", "epi_world_reset", "epi_world_last_flows",
@@ -106,6 +106,8 @@ def lib():
         L.epi_grid_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.epi_world_set_timing.argtypes = [C.c_void_p, C.c_int32]
         L.epi_world_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.epi_gravity_matrix.argtypes = [C.c_int32, _PI, _PD, _PD, _PD, C.c_double, C.c_double, C.c_double, C.c_double,
+                                         C.c_double, _PD, C.c_int32]
         L.epi_grid_destroy.argtypes = [C.c_void_p]
         for name in ("epi_world_destroy", "epi_world_reset"):
             getattr(L, name).argtypes = [C.c_void_p]

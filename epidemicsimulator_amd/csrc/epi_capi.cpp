@@ -1070,6 +1070,38 @@ EPI_API int32_t epi_calibrate_grid(const epi_grid_desc* desc, double* loss, int3
 }
 
 // ================================================================================================
+// graph construction
+// ================================================================================================
+EPI_API int32_t epi_gravity_matrix(int32_t n, const int32_t* pop, const double* lat, const double* lon, const double* flight_mul,
+                                   double a, double b, double g, double k, double cap_row, double* W, int32_t device) {
+    if (n < 0 || (n > 0 && (!pop || !lat || !lon || !W))) return fail(EPI_ERR_BAD_ARGUMENT, "epi_gravity_matrix: null argument");
+    if (n == 0) return EPI_OK;
+    for (int i = 0; i < n; ++i)
+        if (pop[i] < 0 || !std::isfinite(lat[i]) || !std::isfinite(lon[i]))
+            return fail(EPI_ERR_BAD_ARGUMENT, "epi_gravity_matrix: country %d: pop must be >= 0 and lat/lon finite", i);
+    int32_t rc = use_device(device);
+    if (rc) return rc;
+    const size_t nn = (size_t)n * n;
+    DevBuf dpop, dlat, dlon, dfl, dW;
+    HIP_TRY(dpop.upload(std::vector<int32_t>(pop, pop + n)));
+    HIP_TRY(dlat.upload(std::vector<double>(lat, lat + n)));
+    HIP_TRY(dlon.upload(std::vector<double>(lon, lon + n)));
+    if (flight_mul) {
+        HIP_TRY(dfl.ensure(nn * sizeof(double)));
+        HIP_TRY(hipMemcpy(dfl.p, flight_mul, nn * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(dW.ensure(nn * sizeof(double)));
+    GravityArgs ga{};
+    ga.n = n; ga.pop = dpop.as<int32_t>(); ga.lat = dlat.as<double>(); ga.lon = dlon.as<double>();
+    ga.flight = flight_mul ? dfl.as<double>() : nullptr;
+    ga.a = a; ga.b = b; ga.g = g; ga.k = k; ga.cap_row = cap_row;
+    ga.W = dW.as<double>();
+    HIP_TRY(launch_gravity(ga, nullptr));
+    HIP_TRY(hipMemcpy(W, dW.p, nn * sizeof(double), hipMemcpyDeviceToHost));
+    return EPI_OK;
+}
+
+// ================================================================================================
 // batched worlds
 // ================================================================================================
 static int32_t world_build(epi_world* Wd, const epi_world_desc* d) {

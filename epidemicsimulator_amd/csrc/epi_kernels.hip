@@ -1045,4 +1045,66 @@ hipError_t launch_world_unpack(const WorldIoArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// ToyConn.gravityMatrix (ToyConn.scala:22-47) with Geo.haversineKm (Geo.scala:72-79): one workgroup
+// per row i.  The threads fill the row tile by tile; one thread adds the tile up from left to right
+// (the reference's rowSum order) before all of them apply the row cap.  pow / sin / cos / atan2 are
+// the device library's: like the JVM's intrinsics against a host libm, they may differ from another
+// implementation in the last place, so the matrix is an input of the engine, not a pinned output.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGravityTile = 4096;
+
+__device__ __forceinline__ double haversine_km(double lat1, double lon1, double lat2, double lon2) {
+    const double rad = 0.017453292519943295;  // Math.toRadians
+    const double dLat = (lat2 - lat1) * rad, dLon = (lon2 - lon1) * rad;
+    const double sa = sin(dLat / 2), so = sin(dLon / 2);
+    const double h = sa * sa + cos(lat1 * rad) * cos(lat2 * rad) * (so * so);  // Math.pow(x, 2) == x * x exactly
+    const double c = 2 * atan2(sqrt(h), sqrt(1 - h));
+    return 6371.0 * c;
+}
+
+__global__ __launch_bounds__(256) void gravity_rows_kernel(const GravityArgs a) {
+    __shared__ double tile[kGravityTile];
+    __shared__ double sh_sum;
+    const int i = blockIdx.x, n = a.n;
+    const double lat_i = a.lat[i], lon_i = a.lon[i];
+    const double pa = pow((double)a.pop[i], a.a);
+    double* __restrict__ row = a.W + (size_t)i * n;
+    if (threadIdx.x == 0) sh_sum = 0.0;
+    for (int j0 = 0; j0 < n; j0 += kGravityTile) {
+        const int cnt = min(kGravityTile, n - j0);
+        for (int jj = threadIdx.x; jj < cnt; jj += blockDim.x) {
+            const int j = j0 + jj;
+            double w = 0.0;
+            if (j != i) {
+                const double d = fmax(300.0, haversine_km(lat_i, lon_i, a.lat[j], a.lon[j]));
+                const double f = a.flight ? a.flight[(size_t)i * n + j] : 1.0;
+                w = a.k * pa * pow((double)a.pop[j], a.b) * f / pow(d, a.g);
+            }
+            tile[jj] = w;
+            row[j] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = sh_sum;
+            for (int jj = 0; jj < cnt; ++jj)
+                if (j0 + jj != i) s += tile[jj];
+            sh_sum = s;
+        }
+        __syncthreads();
+    }
+    const double row_sum = sh_sum;
+    if (row_sum > 0) {
+        const double scale = fmin(1.0, a.cap_row / row_sum);
+        for (int j = threadIdx.x; j < n; j += blockDim.x)
+            if (j != i) row[j] *= scale;
+    }
+}
+
+hipError_t launch_gravity(const GravityArgs& a, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gravity_rows_kernel, dim3((unsigned)a.n), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 }  // namespace epi

@@ -144,6 +144,16 @@ struct WorldIoArgs {
     int32_t* actions_out;     // [batch][n]
 };
 
+// ToyConn.gravityMatrix (ToyConn.scala:22-47) for n countries: one workgroup per row.
+struct GravityArgs {
+    int n;
+    const int32_t* pop; const double* lat; const double* lon;
+    const double* flight;  // [n][n] flightMul((ci, cj)) or NULL = 1.0 everywhere
+    double a, b, g, k, cap_row;
+    double* W;             // [n][n] out
+};
+
+hipError_t launch_gravity(const GravityArgs& a, hipStream_t s);
 hipError_t launch_world_pack(const WorldIoArgs& a, hipStream_t s);
 hipError_t launch_world_unpack(const WorldIoArgs& a, hipStream_t s);
 hipError_t launch_episode(const EpisodeArgs& a, hipStream_t s);

@@ -90,6 +90,15 @@ int32_t epi_env_step_batch(const epi_env_params *env, const epi_profile *prof, c
  * same operation order). */
 int32_t epi_scale_row(const double *W, int32_t n, int32_t row, double factor, double *out);
 
+/* ---- ToyConn.gravityMatrix (ToyConn.scala:22-47) with Geo.haversineKm (Geo.scala:72-79) --------- */
+/* W[n*n] row-major for n countries (pop, lat, lon), computed on `device`.  flight_mul[n*n] holds
+ * flightMul((ci, cj)) (ToyConn.scala:16-20) or is NULL for 1.0 everywhere.  The reference's defaults are
+ * a = 0.2, b = 1.0, g = 1.2, k = 1e-6, cap_row = 0.12.  The transcendental functions are the device
+ * library's: entries may differ from a JVM or host-libm evaluation in the last place. */
+int32_t epi_gravity_matrix(int32_t n, const int32_t *pop, const double *lat, const double *lon,
+                           const double *flight_mul, double a, double b, double g, double k, double cap_row,
+                           double *W, int32_t device);
+
 /* ---- JVM-compatible streams (scala.util.Random at env.scala:42,91; DDQNAgent.scala:14-32;
  *      MLP.scala:5-9) ------------------------------------------------------------------------- */
 int32_t epi_java_gaussians(int64_t seed, int32_t n, double *out);

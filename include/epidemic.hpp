@@ -155,6 +155,23 @@ inline Matrix gravityMatrix(const std::vector<Geo::Country>& cs, double a = 0.2,
     }
     return W;
 }
+// gravityMatrix computed on the GPU (large synthetic graphs).  Entries may differ from gravityMatrix() in the
+// last place: the device library's pow/sin/cos/atan2 are not the host's.
+inline Matrix gravityMatrixDevice(const std::vector<Geo::Country>& cs, double a = 0.2, double b = 1.0, double g = 1.2, double k = 1e-6,
+                                  double capRow = 0.12) {
+    const int n = (int)cs.size();
+    std::vector<int32_t> pop;
+    std::vector<double> lat, lon, fl((size_t)n * n, 1.0), flat((size_t)n * n, 0.0);
+    for (const auto& c : cs) { pop.push_back(c.pop); lat.push_back(c.lat); lon.push_back(c.lon); }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) fl[(size_t)i * n + j] = flightMul(cs[i].name, cs[j].name);
+    check(epi_gravity_matrix(n, pop.data(), lat.data(), lon.data(), fl.data(), a, b, g, k, capRow, flat.data(), 0));
+    Matrix W((size_t)n, std::vector<double>((size_t)n));
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) W[i][j] = flat[(size_t)i * n + j];
+    return W;
+}
+
 inline const Matrix& W() {
     static const Matrix w = gravityMatrix(C());
     return w;

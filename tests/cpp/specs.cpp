@@ -42,6 +42,13 @@ static void mobilitySpec() {
         EXPECT(W[i][i] == 0.0);
         EXPECT(std::accumulate(W[i].begin(), W[i].end(), 0.0) <= 0.12 + 1e-12);
     }
+    // the same properties for the matrix built on the device, which agrees with the host one to the last places
+    const Matrix Wd = ToyConn::gravityMatrixDevice(ToyConn::C());
+    for (int i = 0; i < n; ++i) {
+        EXPECT(Wd[i][i] == 0.0);
+        EXPECT(std::accumulate(Wd[i].begin(), Wd[i].end(), 0.0) <= 0.12 + 1e-12);
+        for (int j = 0; j < n; ++j) EXPECT(std::fabs(Wd[i][j] - W[i][j]) <= 1e-12 * W[i][j]);
+    }
     const double S[6] = {1000000, 120000, 1000000, 80000, 60000, 300000};
     const double I[6] = {1000, 200, 900, 100, 80, 400};
     std::vector<long long> movedS(n, 0), movedI(n, 0);

@@ -555,3 +555,33 @@ def test_snapshot_stream_records(epi, tmp_path):
     assert not [f for f in (tmp_path / "stream_in" / "snapshots").iterdir() if f.name.endswith(".tmp")]
     w.reset_to_initial()
     assert all(nd.arrival == -1 and nd.peak_i == 0.0 for nd in w.nodes)
+
+
+# ---------------------------------------------------------------- graph construction on the device
+@pytest.mark.parametrize("n", [6, 300, 4500])
+def test_gravity_matrix_on_device(epi, n):
+    """ToyConn.gravityMatrix on the GPU against the host evaluation: the device library's pow/sin/cos/atan2 may
+    differ from the host libm in the last places (tolerance 1e-12 relative, stated here because no integer or
+    pinned value exists for this function); MobilitySpec.scala:7-14's properties hold exactly."""
+    from epidemicsimulator_amd import synth
+    if n == 6:
+        countries = list(epi.ToyConn.C)
+        want = epi.ToyConn.W
+    else:
+        countries, _ = synth.make_countries(n, 11)
+        pop = np.array([c.pop for c in countries], dtype=np.float64)
+        lat_d = np.array([c.lat for c in countries]); lon_d = np.array([c.lon for c in countries])
+        lat = np.radians(lat_d)   # Geo.scala:74-76: toRadians of the DIFFERENCES, and of each latitude
+        h = np.sin(np.radians(lat_d[None, :] - lat_d[:, None]) / 2) ** 2 + np.cos(lat)[:, None] * np.cos(lat)[None, :] * np.sin(np.radians(lon_d[None, :] - lon_d[:, None]) / 2) ** 2
+        d = np.maximum(300.0, 6371.0 * 2 * np.arctan2(np.sqrt(h), np.sqrt(1 - h)))
+        want = 1e-6 * pop[:, None] ** 0.2 * pop[None, :] ** 1.0 / d ** 1.2
+        np.fill_diagonal(want, 0.0)
+        want *= np.minimum(1.0, 0.12 / want.sum(axis=1))[:, None]
+    got = epi.ToyConn.gravity_matrix_device(countries)
+    assert got.shape == (n, n)
+    assert (np.diag(got) == 0.0).all()
+    assert (got.sum(axis=1) <= 0.12 + 1e-12).all() and (got >= 0).all()
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+    if n == 300:  # the device-built matrix is a valid engine input: sparse form of it runs and conserves mass
+        rp, col, val = epi.ToyConn.to_csr(got, threshold=np.quantile(got, 0.9))
+        assert rp[-1] == len(col) == len(val) and (np.diff(rp) > 0).all()
