@@ -410,8 +410,28 @@ __device__ __forceinline__ void apportion_row(int32_t E, int n, int diag, const 
         hint = (uint32_t)__builtin_amdgcn_readfirstlane(__double2hiint(qtop[E - 1] * Ed));
     bool found = false;
     uint32_t mid = 0u;
+    // A bracket end that was probed and is within kSnap elements of the target is moved element by
+    // element instead: the smallest key >= lo (or the largest key < hi) is an exact next threshold, found
+    // with one min (max) reduction, and the probe that follows it always makes progress.
+    constexpr int kSnap = (R <= 4) ? 3 : 1;
     while (hi - lo > 1u) {
-        if (it == 0 && hint != 0u) {
+        if (lo_probed && clo - rem <= kSnap && !(hi_probed && rem - chi < clo - rem)) {
+            uint32_t x = 0xffffffffu;
+#pragma unroll
+            for (int r = 0; r < R; ++r) x = min(x, key[r] >= lo ? key[r] : 0xffffffffu);
+            x = wave_min(x);          // lo <= x < hi, and no key lies in [lo, x)
+            lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+            if (hi - lo <= 1u) break;  // every key of the bracket shares one high word: tie
+            mid = lo + 1u;
+        } else if (hi_probed && rem - chi <= kSnap) {
+            uint32_t y = 0u;
+#pragma unroll
+            for (int r = 0; r < R; ++r) y = max(y, key[r] < hi ? key[r] : 0u);
+            y = wave_max(y);          // lo <= y < hi, and no key lies in (y, hi)
+            hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)y) + 1u;
+            if (hi - lo <= 1u) break;
+            mid = hi - 1u;
+        } else if (it == 0 && hint != 0u) {
             mid = hint;
         } else if (!cold && it < 4 && !(lo_probed && hi_probed)) {
             const uint32_t bk = it == 0 ? pk : last_k;

@@ -95,20 +95,28 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
         int32_t eS = 0, eI = 0;
         unsigned long long mass_local = 0ull;
         if (real) {
+            // the index is made opaque so that the addresses are formed here, every step: precomputed ahead
+            // of the step loop they are kept in scratch memory and each load waits for its address first
+            int ix = tid;
+            asm volatile("" : "+v"(ix));
             StepConsts c;
-            c.beta0 = a.beta0[(size_t)bi * NP + tid];
-            c.gamma = a.cst[CST_GAMMA * NP + tid];
-            c.ifr0 = a.cst[CST_IFR0 * NP + tid];
-            c.cnoise = a.cst[CST_CNOISE * NP + tid];
-            c.eff1 = a.cst[CST_EFF1 * NP + tid];
-            c.eff2 = a.cst[CST_EFF2 * NP + tid];
-            c.eff3 = a.cst[CST_EFF3 * NP + tid];
-            c.surge = a.cst[CST_SURGE * NP + tid];
-            c.vax6 = a.cst[CST_VAX6 * NP + tid];
-            c.vax7 = a.cst[CST_VAX7 * NP + tid];
-            int act = a.act_episode ? (int)a.act_episode[eoff + tid] : (int)a.actions[(size_t)(t - a.act_t0) * NP + tid];
+            c.beta0 = a.beta0[(size_t)bi * NP + ix];
+            c.gamma = a.cst[CST_GAMMA * NP + ix];
+            c.ifr0 = a.cst[CST_IFR0 * NP + ix];
+            c.cnoise = a.cst[CST_CNOISE * NP + ix];
+            c.eff1 = a.cst[CST_EFF1 * NP + ix];
+            c.eff2 = a.cst[CST_EFF2 * NP + ix];
+            c.eff3 = a.cst[CST_EFF3 * NP + ix];
+            c.surge = a.cst[CST_SURGE * NP + ix];
+            c.vax6 = a.cst[CST_VAX6 * NP + ix];
+            c.vax7 = a.cst[CST_VAX7 * NP + ix];
+            int act = a.act_episode ? (int)a.act_episode[eoff + ix] : (int)a.actions[(size_t)(t - a.act_t0) * NP + ix];
             act = act < 0 ? 0 : (act > 7 ? 7 : act);  // Action.fromId clamps (env.scala:18-20)
-            const double z = a.noise_episode ? a.noise_episode[eoff + tid] : a.noise[(size_t)(t - a.noise_t0) * NP + tid];
+            const double z = a.noise_episode ? a.noise_episode[eoff + ix] : a.noise[(size_t)(t - a.noise_t0) * NP + ix];
+            // all constants in one batch of loads: those that only some actions use would otherwise be fetched
+            // inside the action branches, one exposed memory latency each
+            keep_loaded(c.eff1); keep_loaded(c.eff2); keep_loaded(c.eff3); keep_loaded(c.surge);
+            keep_loaded(c.vax6); keep_loaded(c.vax7); keep_loaded(c.ifr0); keep_loaded(c.cnoise);
             const int32_t s0 = sh_s[tid], i0 = sh_i[tid], r0 = sh_r[tid], d0 = sh_d[tid], v0 = sh_v[tid];
             const double cap0 = sh_cap[tid];
             const long long tb = (long long)s0 + i0 + r0 + d0 + v0;
