@@ -413,7 +413,7 @@ __device__ __forceinline__ void apportion_row(int32_t E, int n, int diag, const 
     // A bracket end that was probed and is within kSnap elements of the target is moved element by
     // element instead: the smallest key >= lo (or the largest key < hi) is an exact next threshold, found
     // with one min (max) reduction, and the probe that follows it always makes progress.
-    constexpr int kSnap = (R <= 4) ? 3 : 1;
+    constexpr int kSnap = (R <= 4) ? 2 : 1;  // measured best on the 200- and the 1,000-country grids
     while (hi - lo > 1u) {
         if (lo_probed && clo - rem <= kSnap && !(hi_probed && rem - chi < clo - rem)) {
             uint32_t x = 0xffffffffu;
