@@ -315,6 +315,63 @@ def test_grid_full_size_properties(epi):
     np.testing.assert_allclose(got["loss"], want["loss"], rtol=1e-12, atol=0)
 
 
+def test_grid_full_size_c3(epi):
+    """Configuration 3 at full size (1,000 countries, 64x64, T=200): the same size-independent properties, slabs
+    of the flat grid as the 8-GPU run cuts them, and one grid point against the oracle."""
+    from epidemicsimulator_amd import synth
+    from epidemicsimulator_amd.dist import slab_bounds
+    wl = synth.workload("c3")
+    base = synth.base_state(wl["steps"])
+    eng = epi.GridEngine(epi.HyperParams(), wl["steps"], base, 0, [c.pop for c in wl["countries"]], wl["conn"],
+                         wl["profiles"], wl["betas"], wl["travel"], wl["t_arrive"], wl["t_peak"], True)
+    out = eng.run(want_metrics=False)
+    assert np.isfinite(out["loss"]).all() and (out["loss"] >= 0).all() and len(out["loss"]) == 4096
+    g0, cnt, per = slab_bounds(4096, 8, 5)     # rank 5 of 8: grid points 2560..3071
+    assert (g0, cnt, per) == (2560, 512, 512)
+    slab = eng.run(g0, cnt)
+    np.testing.assert_array_equal(slab["loss"], out["loss"][g0:g0 + cnt])
+    assert (slab["arrival"] >= 0).all() and (slab["arrival"] <= wl["steps"]).all() and (slab["arrival"][:, 0] == 0).all()
+    eng.close()
+    g = 37 * 64 + 11
+    wl1 = dict(wl); wl1["betas"], wl1["travel"] = [wl["betas"][37]], [wl["travel"][11]]
+    want = util.oracle_grid(wl1, base)
+    assert want["err"] == 0
+    got = util.engine_grid(wl1, base)
+    np.testing.assert_array_equal(got["arrival"], want["arrival"])
+    np.testing.assert_array_equal(got["peak"], want["peak"])
+    np.testing.assert_allclose(got["loss"], want["loss"], rtol=1e-12, atol=0)
+    assert got["loss"][0] == out["loss"][g]
+
+
+def test_grid_full_size_c4(epi):
+    """Configuration 4 at full size (20,000 patches, CSR, 16x16, T=200): properties and slab invariance on the
+    whole sweep, and the first two steps of one grid point against the oracle (which walks dense rows)."""
+    from epidemicsimulator_amd import synth
+    wl = synth.workload("c4")
+    n = len(wl["countries"])
+    base = synth.base_state(wl["steps"])
+    eng = epi.GridEngine(epi.HyperParams(), wl["steps"], base, 0, [c.pop for c in wl["countries"]], wl["conn"],
+                         wl["profiles"], wl["betas"], wl["travel"], wl["t_arrive"], wl["t_peak"], True)
+    out = eng.run()
+    assert np.isfinite(out["loss"]).all() and len(out["loss"]) == 256
+    assert (out["arrival"] >= 0).all() and (out["arrival"] <= wl["steps"]).all() and (out["arrival"][:, 0] == 0).all()
+    assert ((out["arrival"] < wl["steps"]).sum(axis=1) > n // 2).all(), "the infection reaches most patches in 200 steps"
+    for g in (0, 100, 255):
+        one = eng.run(g, 1)
+        assert one["loss"][0] == out["loss"][g]
+        np.testing.assert_array_equal(one["arrival"][0], out["arrival"][g])
+        np.testing.assert_array_equal(one["peak"][0], out["peak"][g])
+    eng.close()
+    steps = 2
+    wl2 = dict(wl); wl2["steps"] = steps
+    wl2["betas"], wl2["travel"] = [wl["betas"][9]], [wl["travel"][4]]
+    wl2["t_arrive"], wl2["t_peak"] = synth.targets(n, steps)
+    b2 = synth.base_state(steps)
+    want = util.oracle_grid(wl2, b2)
+    assert want["err"] == 0
+    util.assert_grid_equal(util.engine_grid(wl2, b2), want)
+
+
 # ---------------------------------------------------------------- sparse (CSR) worlds, n > 1024
 def _sparse_workload(n, deg, nb, nt, steps, seed):
     from epidemicsimulator_amd import synth
