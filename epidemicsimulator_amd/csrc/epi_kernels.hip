@@ -262,9 +262,9 @@ constexpr int kCsrThreads = 768;  // 8 waves: room for a whole row of keys per l
 // Address of slot k0 of a lane's row, formed where it is used: the empty asm keeps the compiler from
 // precomputing one 64-bit address per slot ahead of the loops, which costs two registers per slot;
 // the slots of a group are then reached with immediate offsets.
-template <class T>
+template <class T, int STRIDE = 64>
 __device__ __forceinline__ const T* group_ptr(const T* p, int k0) {
-    int off = k0 * 64;
+    int off = k0 * STRIDE;
     asm volatile("" : "+v"(off));
     return p + off;
 }
@@ -278,7 +278,9 @@ struct LaneThreshold {
     uint32_t Kx, picked;
 };
 
-template <int DMAX>
+// STRIDE: distance in elements between consecutive weights of the lane's row (64 in the slot-major
+// layout of sparse graphs, 1 for a plain row).
+template <int DMAX, int STRIDE = 64>
 __device__ __forceinline__ LaneThreshold lane_threshold(uint32_t (&srt)[DMAX], int32_t rem, double Ed, int D,
                                                         const double* __restrict__ qp) {
     // K = the rem-th largest key, read from the sorted keys (sorting network: no data-dependent control
@@ -308,11 +310,11 @@ __device__ __forceinline__ LaneThreshold lane_threshold(uint32_t (&srt)[DMAX], i
 #pragma unroll
             for (int k0 = 0; k0 < DMAX; k0 += kSlotGroup) {
                 if (k0 < D) {
-                    const double* qg = group_ptr(qp, k0);
+                    const double* qg = group_ptr<double, STRIDE>(qp, k0);
 #pragma unroll
                     for (int j = 0; j < kSlotGroup; ++j) {
                         const int k = k0 + j;
-                        const double fr = frac_of(qg[j * 64] * Ed);
+                        const double fr = frac_of(qg[j * STRIDE] * Ed);
                         const bool cand = k < D && m > 0 && (uint32_t)__double2hiint(fr) == K && !((r.picked >> k) & 1u) && fr > best;
                         if (cand) { best = fr; best_k = k; }
                     }
@@ -685,6 +687,166 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small dense worlds (n <= 16 countries, e.g. the reference's six-country toy world): one lane per
+// country, one group of 16 lanes per episode, four episodes per wave.  A lane keeps its row of the
+// normalised matrix in registers for the whole launch and splits its exports with the same
+// sorting-network routine as the sparse kernel (lane_threshold); the inflows of an episode are
+// summed through 16 LDS words per compartment.  Same step as the wide kernel (WorldToy.scala:83-145),
+// same selection rule: the rem largest fractions of ALL n columns, ties by column order, the origin's
+// own entry dropped afterwards (WorldToy.scala:121).
+// ---------------------------------------------------------------------------------------------
+constexpr int kTinyN = 16;
+
+__device__ __forceinline__ void tiny_split(int32_t E, const double (&q)[kTinyN], const double* __restrict__ qrow, int n, int c,
+                                           uint32_t* sh_mov) {
+    if (!__any(E > 0)) return;
+    const double Ed = (double)E;
+    uint32_t srt[kTinyN];
+    uint32_t bsum = 0u;
+#pragma unroll
+    for (int j = 0; j < kTinyN; ++j) {
+        const double raw = q[j] * Ed;
+        bsum += (uint32_t)(int32_t)raw;
+        srt[j] = (uint32_t)__double2hiint(frac_of(raw));
+    }
+    const int32_t rem = E > 0 ? (int32_t)((uint32_t)E - bsum) : 0;
+    const LaneThreshold th = lane_threshold<kTinyN, 1>(srt, rem, Ed, n, qrow);
+#pragma unroll
+    for (int j = 0; j < kTinyN; ++j) {
+        const double raw = q[j] * Ed;
+        const uint32_t sel = (uint32_t)((uint32_t)__double2hiint(frac_of(raw)) >= th.Kx) | ((th.picked >> j) & 1u);
+        const uint32_t alloc = (uint32_t)(int32_t)raw + (j < n ? sel : 0u);
+        if (alloc != 0u && j != c) atomicAdd(&sh_mov[j], alloc);
+    }
+}
+
+__global__ __launch_bounds__(64) void episode_tiny_kernel(const EpisodeArgs a) {
+    __shared__ uint32_t sh_movS[4][kTinyN], sh_movI[4][kTinyN];
+    __shared__ unsigned long long sh_mass[4][2];
+    __shared__ int sh_err[4][4];
+    const int lane = threadIdx.x;
+    const int grp = lane >> 4, c = lane & 15;
+    const int e = blockIdx.x * 4 + grp;
+    const int n = a.n;
+    const bool live = e < a.count;
+    const bool real = live && c < n;
+    const int NP = a.npad;  // 64
+    const int g = a.g_begin + (live ? e : 0);
+    const int ti = a.n_travel > 0 ? g % a.n_travel : 0;
+    int bi = a.n_travel > 0 ? g / a.n_travel : g;
+    bi = bi < a.beta_rows ? bi : a.beta_rows - 1;
+    const size_t eoff = (size_t)(live ? e : 0) * NP;
+    const size_t plane = (size_t)a.count * NP;
+    const int cc = c < n ? c : 0;
+
+    int32_t s = a.st[0 * plane + eoff + cc], i = a.st[1 * plane + eoff + cc], r = a.st[2 * plane + eoff + cc];
+    int32_t d = a.st[3 * plane + eoff + cc], v = a.st[4 * plane + eoff + cc];
+    double cap = a.cap[eoff + cc];
+    int32_t tcur = a.tcur[eoff + cc], arrival = a.arrival[eoff + cc], peak = a.peak[eoff + cc];
+    int32_t last_flow_s = 0, last_flow_i = 0;
+    const bool seed_row = (cc == a.seed_idx && a.qseed);
+    const double* __restrict__ qrow = seed_row ? a.qseed + (size_t)ti * NP : a.q + (size_t)cc * NP;
+    const double my_sumw = real ? (seed_row ? a.sumw_seed[ti] : a.sumw[cc]) : 0.0;
+    double q[kTinyN];
+#pragma unroll
+    for (int j = 0; j < kTinyN; ++j) q[j] = real ? qrow[j] : 0.0;
+    StepConsts k;
+    k.beta0 = a.beta0[(size_t)bi * NP + cc];
+    k.gamma = a.cst[CST_GAMMA * NP + cc];
+    k.ifr0 = a.cst[CST_IFR0 * NP + cc];
+    k.cnoise = a.cst[CST_CNOISE * NP + cc];
+    k.eff1 = a.cst[CST_EFF1 * NP + cc];
+    k.eff2 = a.cst[CST_EFF2 * NP + cc];
+    k.eff3 = a.cst[CST_EFF3 * NP + cc];
+    k.surge = a.cst[CST_SURGE * NP + cc];
+    k.vax6 = a.cst[CST_VAX6 * NP + cc];
+    k.vax7 = a.cst[CST_VAX7 * NP + cc];
+    if (c == 0) {
+        sh_mass[grp][0] = sh_mass[grp][1] = 0ull;
+        sh_err[grp][0] = sh_err[grp][1] = sh_err[grp][2] = sh_err[grp][3] = 0;
+    }
+    __syncthreads();
+
+    for (int t = a.t_begin; t < a.t_end; ++t) {
+        // ---- A: local dynamics, exports (WorldToy.scala:83-115)
+        sh_movS[grp][c] = 0u;
+        sh_movI[grp][c] = 0u;
+        int32_t eS = 0, eI = 0;
+        unsigned long long mass_local = 0ull;
+        if (real) {
+            int act = a.act_episode ? (int)a.act_episode[eoff + c] : (int)a.actions[(size_t)(t - a.act_t0) * NP + c];
+            act = act < 0 ? 0 : (act > 7 ? 7 : act);  // Action.fromId clamps (env.scala:18-20)
+            const double z = a.noise_episode ? a.noise_episode[eoff + c] : a.noise[(size_t)(t - a.noise_t0) * NP + c];
+            const long long tb = (long long)s + i + r + d + v;
+            const LocalOut o = local_step(k, s, i, r, d, v, cap, act, z);
+            const long long ta = (long long)o.s + o.i + o.r + o.d + o.v;
+            if (a.validate && ta != tb) record_error(sh_err[grp], EPI_ERR_LOCAL_MASS, c, tcur);
+            if ((o.s | o.i | o.r | o.d | o.v) < 0) record_error(sh_err[grp], EPI_ERR_INT_RANGE, c, tcur);
+            if (a.rwd) a.reward_out[eoff + c] = reward_of(a.rwd[c], (double)i, (double)d, o, act);
+            s = o.s; i = o.i; r = o.r; d = o.d; v = o.v;
+            cap = o.cap;
+            tcur += 1;  // env.scala:132
+            eS = export_count(max(0, s), my_sumw);
+            eI = export_count(max(0, i), my_sumw);
+            mass_local = ta > 0 ? (unsigned long long)ta : 0ull;
+        }
+        if (a.validate && mass_local) atomicAdd(&sh_mass[grp][0], mass_local);
+        __syncthreads();
+        // ---- B: mobility (WorldToy.scala:106-126), every lane splits its own row
+        tiny_split(eS, q, qrow, n, c, sh_movS[grp]);
+        tiny_split(eI, q, qrow, n, c, sh_movI[grp]);
+        __syncthreads();
+        // ---- C: apply, metrics, world mass (WorldToy.scala:128-145)
+        unsigned long long mass_move = 0ull;
+        if (real) {
+            const int32_t movedS = (int32_t)(sh_movS[grp][c] - (uint32_t)eS);
+            const int32_t movedI = (int32_t)(sh_movI[grp][c] - (uint32_t)eI);
+            const double ns = fmax(0.0, (double)s + (double)movedS);
+            const double ni = fmax(0.0, (double)i + (double)movedI);
+            if (ns > 2147483647.0 || ni > 2147483647.0) record_error(sh_err[grp], EPI_ERR_INT_RANGE, c, tcur);
+            s = (int32_t)ns;
+            i = (int32_t)ni;
+            tcur = min(tcur + 1, a.step_t_max);
+            if (arrival < 0 && i >= 10) arrival = t;
+            peak = max(peak, i);
+            last_flow_s = movedS;
+            last_flow_i = movedI;
+            const long long tm = (long long)s + i + r + d + v;
+            mass_move = tm > 0 ? (unsigned long long)tm : 0ull;
+        }
+        if (a.validate && mass_move) atomicAdd(&sh_mass[grp][1], mass_move);
+        __syncthreads();
+        if (a.validate && c == 0) {
+            if (sh_mass[grp][0] != sh_mass[grp][1]) record_error(sh_err[grp], EPI_ERR_WORLD_MASS, -1, t);
+            sh_mass[grp][0] = sh_mass[grp][1] = 0ull;
+        }
+        // the next step's phase A adds to sh_mass[grp][0] only after the barrier that follows its own
+        // LDS writes; lane c == 0 of the group cleared the sums above, in program order of the same wave
+    }
+    __syncthreads();
+    if (live && c == 0 && sh_err[grp][0] != 0 && a.err[e * 4] == 0) {
+        a.err[e * 4 + 1] = sh_err[grp][1];
+        a.err[e * 4 + 2] = sh_err[grp][2];
+        a.err[e * 4] = sh_err[grp][0];
+    }
+    if (real) {
+        a.st[0 * plane + eoff + c] = s;
+        a.st[1 * plane + eoff + c] = i;
+        a.st[2 * plane + eoff + c] = r;
+        a.st[3 * plane + eoff + c] = d;
+        a.st[4 * plane + eoff + c] = v;
+        a.cap[eoff + c] = cap;
+        a.tcur[eoff + c] = tcur;
+        a.arrival[eoff + c] = arrival;
+        a.peak[eoff + c] = peak;
+        if (a.flow_s) {
+            a.flow_s[eoff + c] = last_flow_s;
+            a.flow_i[eoff + c] = last_flow_i;
+        }
+    }
+}
+
 size_t csr_lds_bytes(int n) { return (((size_t)n * 8 + 15) & ~(size_t)15) + 4 * sizeof(unsigned long long) + 4 * sizeof(int); }
 
 template <int DMAX>
@@ -705,6 +867,10 @@ hipError_t launch_episode(const EpisodeArgs& a, hipStream_t s) {
         if (a.max_deg <= 24) return launch_csr<24>(a, s);
         if (a.max_deg <= kLaneSlots) return launch_csr<kLaneSlots>(a, s);
         return hipErrorInvalidValue;
+    }
+    if (a.n <= kTinyN && a.npad == 64) {
+        hipLaunchKernelGGL(episode_tiny_kernel, dim3((unsigned)((a.count + 3) / 4)), dim3(64), 0, s, a);
+        return hipGetLastError();
     }
     const dim3 grid((unsigned)a.count);
     switch (a.npad / 64) {

@@ -523,7 +523,7 @@ def test_grid_empty_and_degenerate_axes(epi):
             assert (got["arrival"] == 0).all() and (got["peak"] == 0).all()
 
 
-@pytest.mark.parametrize("n,seed_idx", [(1, 0), (2, 1), (64, 63), (65, 64), (1024, 517)])
+@pytest.mark.parametrize("n,seed_idx", [(1, 0), (2, 1), (13, 12), (16, 15), (17, 3), (64, 63), (65, 64), (1024, 517)])
 def test_grid_sizes_and_seed_positions(epi, n, seed_idx):
     """One country, wave-boundary sizes, the widest dense world (1,024) and seeds other than country 0."""
     from epidemicsimulator_amd import synth
