@@ -167,7 +167,7 @@ def run_c5(args, rank, local_rank, world, use_dist):
                    "parallelism": "independent replicas" if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": traffic_src, "kernel": "episode_dense_kernel",
+                     "traffic_source": traffic_src, "kernel": "episode_tiny_kernel",
                      "launches": int(k_launches), "avg_launch_ms": k_ms / max(1, k_launches),
                      "algorithmic_bytes_per_country_step": bpcs,
                      "algorithmic_bytes_per_launch": B * n * bpcs,
@@ -286,7 +286,8 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": ("%s: per-launch (FETCH_SIZE*2 + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes "
                                         "of this command" % traffic_src) if traffic_src else None,
-                     "kernel": "episode_csr_kernel" if isinstance(wl["conn"], tuple) else "episode_dense_kernel",
+                     "kernel": "episode_csr_kernel" if isinstance(wl["conn"], tuple) else (
+                         "episode_tiny_kernel" if n <= 16 else "episode_dense_kernel"),
                      "launches": int(k_launches),
                      "avg_launch_ms": k_ms / max(1, k_launches),
                      "algorithmic_bytes_per_country_step": bpcs,

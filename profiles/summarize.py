@@ -34,7 +34,7 @@ def counters(path, kernel_sub):
 def main():
     src, out = sys.argv[1], sys.argv[2]
     bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-    kernel_sub = "episode_csr_kernel" if "CSR" in bench["config"]["workload"] else "episode_dense_kernel"
+    kernel_sub = bench["roofline"]["kernel"]
     stats_csv = newest(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")))[0]
     shutil.copy(stats_csv, out + "_kernel_stats.csv")
     kstats = [r for r in csv.DictReader(open(stats_csv)) if kernel_sub in r["Name"]][0]
