@@ -127,8 +127,7 @@ def run_c5(args, rank, local_rank, world, use_dist):
                    device=local_rank)
     rng = np.random.Generator(np.random.PCG64(20251226 + rank))
     acts = rng.integers(0, 8, size=(64, B, n), dtype=np.int32)  # a ring of pre-drawn action batches
-    states = np.empty((B, n), dtype=E.WorldToy.STATE_DTYPE)
-    rewards = np.empty((B, n))
+    states, rewards = w.result_arrays()   # the handle's page-locked result arrays, read in place by the trainer
 
     def fence():
         if use_dist:

@@ -476,6 +476,17 @@ class WorldToy:
             lib().epi_world_destroy(self._h)
             self._h = None
 
+    def result_arrays(self):
+        """(states, rewards): numpy views of the handle's own page-locked result arrays.  Passed as out_states /
+        out_rewards to step_arrays they are filled by the device without a further copy; they are overwritten by
+        the next step and die with the world."""
+        ps = C.c_void_p(); pr = C.c_void_p()
+        check(lib().epi_world_result_buffers(self._h, C.byref(ps), C.byref(pr), None))
+        cells = self.batch * self.n
+        st = np.ctypeslib.as_array(C.cast(ps, C.POINTER(C.c_uint8)), shape=(cells * WorldToy.STATE_DTYPE.itemsize,))
+        rw = np.ctypeslib.as_array(C.cast(pr, C.POINTER(C.c_double)), shape=(cells,))
+        return st.view(WorldToy.STATE_DTYPE).reshape(self.batch, self.n), rw.reshape(self.batch, self.n)
+
     def __del__(self):
         try:
             self.close()

@@ -80,7 +80,7 @@ EXPORTED_SYMBOLS = [
     "epi_mlp_greedy_batch", "epi_grid_create", "epi_grid_run", "epi_grid_status", "epi_grid_destroy",
     "epi_grid_argmin", "epi_calibrate_grid", "epi_grid_set_timing", "epi_grid_kernel_time", "epi_world_create", "epi_world_step", "epi_world_step_greedy",
     "epi_world_set_mlp", "epi_world_get_states", "epi_world_set_states", "epi_world_reset", "epi_world_last_flows",
-    "epi_world_set_timing", "epi_world_kernel_time", "epi_world_destroy",
+    "epi_world_set_timing", "epi_world_kernel_time", "epi_world_result_buffers", "epi_world_destroy",
 ]
 
 _lib = None
@@ -104,6 +104,8 @@ def lib():
         L.epi_grid_status.argtypes = [C.c_void_p]
         L.epi_grid_set_timing.argtypes = [C.c_void_p, C.c_int32]
         L.epi_grid_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.epi_world_result_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_void_p)]
         L.epi_world_set_timing.argtypes = [C.c_void_p, C.c_int32]
         L.epi_world_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.epi_gravity_matrix.argtypes = [C.c_int32, _PI, _PD, _PD, _PD, C.c_double, C.c_double, C.c_double, C.c_double,

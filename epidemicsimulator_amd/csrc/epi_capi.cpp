@@ -85,9 +85,11 @@ struct DevBuf {
     T* as() const { return static_cast<T*>(p); }
 };
 
-// Owning page-locked host allocation (staging for the per-step transfers of the batched worlds).
+// Owning page-locked host allocation, mapped into the device's address space: kernels read and write it
+// directly over PCIe through `dev` (staging for the per-step transfers of the batched worlds).
 struct PinBuf {
     void* p = nullptr;
+    void* dev = nullptr;
     size_t bytes = 0;
     PinBuf() = default;
     PinBuf(const PinBuf&) = delete;
@@ -96,14 +98,18 @@ struct PinBuf {
     hipError_t ensure(size_t want) {
         if (want <= bytes && p) return hipSuccess;
         if (p) (void)hipHostFree(p);
-        p = nullptr; bytes = 0;
+        p = dev = nullptr; bytes = 0;
         if (want == 0) want = 16;
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);
+        if (e != hipSuccess) return e;
+        e = hipHostGetDevicePointer(&dev, p, 0);
         if (e == hipSuccess) bytes = want;
         return e;
     }
     template <class T>
     T* as() const { return static_cast<T*>(p); }
+    template <class T>
+    T* on_device() const { return static_cast<T*>(dev); }
 };
 
 const epi_profile kDefaultProfile = {1.0, 1.0, 0.05, 100.0, 30000.0, 0.7, 0.15, 0.8, 0.7};  // Geo.scala:4-21
@@ -507,9 +513,9 @@ struct epi_world {
     bool mlp_set = false;
     EpisodeBuffers work;
     DevBuf act_dev, gauss_dev, reward_dev, flow_s, flow_i, q_tmp;
-    // compact [batch][n] images of the caller's arrays: device side and page-locked host side
-    DevBuf in_act, in_gauss, out_states, out_rewards, out_actions;
+    // compact [batch][n] images of the caller's arrays in page-locked, device-mapped host memory
     PinBuf pin_act, pin_gauss, pin_states, pin_rewards, pin_actions, pin_err;
+
     std::vector<JavaRandom> env_rnd;  // one stream per country (env.scala:42)
     std::vector<int32_t> env_seeds;
     bool have_flows = false;
@@ -1156,11 +1162,6 @@ static int32_t world_build(epi_world* Wd, const epi_world_desc* d) {
     HIP_TRY(Wd->flow_i.ensure(cells * sizeof(int32_t)));
     if (cells > (size_t)1 << 30) return fail(EPI_ERR_UNSUPPORTED, "world: batch x padded countries = %zu exceeds 2^30 cells", cells);
     const size_t compact = (size_t)d->batch * n;
-    HIP_TRY(Wd->in_act.ensure(compact * sizeof(int32_t)));
-    HIP_TRY(Wd->in_gauss.ensure(compact * sizeof(double)));
-    HIP_TRY(Wd->out_states.ensure(compact * sizeof(epi_state)));
-    HIP_TRY(Wd->out_rewards.ensure(compact * sizeof(double)));
-    HIP_TRY(Wd->out_actions.ensure(compact * sizeof(int32_t)));
     HIP_TRY(Wd->pin_act.ensure(compact * sizeof(int32_t)));
     HIP_TRY(Wd->pin_gauss.ensure(compact * sizeof(double)));
     HIP_TRY(Wd->pin_states.ensure(compact * sizeof(epi_state)));
@@ -1216,12 +1217,19 @@ static void world_io_args(const epi_world* w, WorldIoArgs& io) {
 static int32_t world_download_states(epi_world* w, epi_state* out) {
     WorldIoArgs io{};
     world_io_args(w, io);
-    io.states_out = w->out_states.as<epi_state>();
+    io.states_out = w->pin_states.on_device<epi_state>();
     const size_t bytes = (size_t)w->batch * w->n * sizeof(epi_state);
     HIP_TRY(launch_world_unpack(io, nullptr));
-    HIP_TRY(hipMemcpyAsync(w->pin_states.p, w->out_states.p, bytes, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
     std::memcpy(out, w->pin_states.p, bytes);
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_world_result_buffers(epi_world* w, epi_state** states, double** rewards, int32_t** actions) {
+    if (!w) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_result_buffers: null handle");
+    if (states) *states = w->pin_states.as<epi_state>();
+    if (rewards) *rewards = w->pin_rewards.as<double>();
+    if (actions) *actions = w->pin_actions.as<int32_t>();
     return EPI_OK;
 }
 
@@ -1274,6 +1282,7 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
     hipStream_t s = nullptr;
     WorldIoArgs io{};
     world_io_args(w, io);
+    // Inputs are placed in mapped page-locked memory and read by the pack kernel over PCIe: no copy calls.
     // noise draws: caller-supplied, or one JVM-compatible stream per country shared by all instances
     double* hz = w->pin_gauss.as<double>();
     if (gauss) {
@@ -1282,17 +1291,14 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
                 return fail(EPI_ERR_BAD_ARGUMENT, "world step: gauss[%d][%d] is not finite", (int)(k / n), (int)(k % n));
             hz[k] = gauss[k];
         }
-        HIP_TRY(hipMemcpyAsync(w->in_gauss.p, hz, compact * sizeof(double), hipMemcpyHostToDevice, s));
-        io.gauss = w->in_gauss.as<double>();
+        io.gauss = w->pin_gauss.on_device<double>();
     } else {
         for (int c = 0; c < n; ++c) hz[c] = w->env_rnd[c].nextGaussian();
-        HIP_TRY(hipMemcpyAsync(w->in_gauss.p, hz, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
-        io.gauss_row = w->in_gauss.as<double>();
+        io.gauss_row = w->pin_gauss.on_device<double>();
     }
     if (!greedy) {
         std::memcpy(w->pin_act.p, actions, compact * sizeof(int32_t));
-        HIP_TRY(hipMemcpyAsync(w->in_act.p, w->pin_act.p, compact * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        io.actions = w->in_act.as<int32_t>();
+        io.actions = w->pin_act.on_device<int32_t>();
     }
     HIP_TRY(launch_world_pack(io, s));
     if (greedy) {
@@ -1325,18 +1331,13 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
     if (w->timing) HIP_TRY(hipEventRecord(w->ev0, s));
     HIP_TRY(launch_episode(ea, s));
     if (w->timing) HIP_TRY(hipEventRecord(w->ev1, s));
-    // results: compact on the device, then one transfer per requested array into page-locked memory
-    if (out_states) io.states_out = w->out_states.as<epi_state>();
-    if (out_rewards) io.rewards_out = w->out_rewards.as<double>();
-    if (out_actions) io.actions_out = w->out_actions.as<int32_t>();
-    if (out_states || out_rewards || out_actions) HIP_TRY(launch_world_unpack(io, s));
-    HIP_TRY(hipMemcpyAsync(w->pin_err.p, w->work.err.p, (size_t)B * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (out_states)
-        HIP_TRY(hipMemcpyAsync(w->pin_states.p, w->out_states.p, compact * sizeof(epi_state), hipMemcpyDeviceToHost, s));
-    if (out_rewards)
-        HIP_TRY(hipMemcpyAsync(w->pin_rewards.p, w->out_rewards.p, compact * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (out_actions)
-        HIP_TRY(hipMemcpyAsync(w->pin_actions.p, w->out_actions.p, compact * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    // Results: the unpack kernel writes compact records straight into the handle's page-locked, device-mapped
+    // result arrays; a caller that reads them in place (epi_world_result_buffers) gets no further copy.
+    if (out_states) io.states_out = w->pin_states.on_device<epi_state>();
+    if (out_rewards) io.rewards_out = w->pin_rewards.on_device<double>();
+    if (out_actions) io.actions_out = w->pin_actions.on_device<int32_t>();
+    io.err_out = w->pin_err.on_device<int32_t>();
+    HIP_TRY(launch_world_unpack(io, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (w->timing) {
         float ms = 0.f;
@@ -1346,14 +1347,14 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
         w->kernel_country_steps += (long long)B * n;
     }
     w->have_flows = true;
+    if (out_states && out_states != w->pin_states.p) std::memcpy(out_states, w->pin_states.p, compact * sizeof(epi_state));
+    if (out_rewards && out_rewards != w->pin_rewards.p) std::memcpy(out_rewards, w->pin_rewards.p, compact * sizeof(double));
+    if (out_actions && out_actions != w->pin_actions.p) std::memcpy(out_actions, w->pin_actions.p, compact * sizeof(int32_t));
     const int32_t* he = w->pin_err.as<int32_t>();
     for (int e = 0; e < B; ++e)
         if (he[(size_t)e * 4] != 0)
             return fail(he[(size_t)e * 4], "%s (instance %d, country %d, t=%d)", status_text(he[(size_t)e * 4]), e,
                         he[(size_t)e * 4 + 1], he[(size_t)e * 4 + 2]);
-    if (out_states) std::memcpy(out_states, w->pin_states.p, compact * sizeof(epi_state));
-    if (out_rewards) std::memcpy(out_rewards, w->pin_rewards.p, compact * sizeof(double));
-    if (out_actions) std::memcpy(out_actions, w->pin_actions.p, compact * sizeof(int32_t));
     return EPI_OK;
 }
 

@@ -1182,6 +1182,8 @@ __global__ void world_unpack_kernel(const WorldIoArgs a) {
     const int cells = a.batch * a.n;
     const size_t plane = (size_t)a.batch * a.npad;
     const int stride = gridDim.x * blockDim.x;
+    if (a.err_out)
+        for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < a.batch * 4; k += stride) a.err_out[k] = a.err[k];
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cells; k += stride) {
         const int b = k / a.n, c = k - b * a.n;
         const size_t o = (size_t)b * a.npad + c;
@@ -1215,7 +1217,7 @@ hipError_t launch_world_pack(const WorldIoArgs& a, hipStream_t s) {
 
 hipError_t launch_world_unpack(const WorldIoArgs& a, hipStream_t s) {
     if (a.batch <= 0) return hipSuccess;
-    hipLaunchKernelGGL(world_unpack_kernel, dim3(io_blocks(a.batch * a.n)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(world_unpack_kernel, dim3(io_blocks(a.batch * (a.n > 4 ? a.n : 4))), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

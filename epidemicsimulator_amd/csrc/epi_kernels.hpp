@@ -142,6 +142,7 @@ struct WorldIoArgs {
     epi_state* states_out;    // [batch][n]
     double* rewards_out;      // [batch][n]
     int32_t* actions_out;     // [batch][n]
+    int32_t* err_out;         // [batch][4] copy of the error table (optional)
 };
 
 // ToyConn.gravityMatrix (ToyConn.scala:22-47) for n countries: one workgroup per row.

@@ -195,6 +195,12 @@ epi_world *epi_world_create(const epi_world_desc *desc);
  * world would draw).  out_states[batch][n] / out_rewards[batch][n] may be NULL. */
 int32_t epi_world_step(epi_world *w, const int32_t *actions, const double *gauss, int32_t t_max,
                        epi_state *out_states, double *out_rewards);
+/* Optional (no counterpart in the reference): addresses of the handle's own page-locked result arrays
+ * states[batch][n], rewards[batch][n], actions[batch][n] (any of the three pointers may be NULL).  The device
+ * writes every step's results into them; a caller that passes exactly these addresses as the out_* arguments
+ * of epi_world_step / epi_world_step_greedy reads the results in place, without the copy into caller memory.
+ * They belong to the handle and are overwritten by the next step. */
+int32_t epi_world_result_buffers(epi_world *w, epi_state **states, double **rewards, int32_t **actions);
 /* WorldToy.stepOneGreedy (:172-235): actions = argmax Q(features) with the weights set below. */
 int32_t epi_world_step_greedy(epi_world *w, const double *gauss, int32_t t_max, epi_state *out_states,
                               double *out_rewards, int32_t *out_actions);

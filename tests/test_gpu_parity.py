@@ -186,6 +186,31 @@ def test_world_batch_instances_are_independent(epi):
         np.testing.assert_array_equal(rewards[b], o_r)
 
 
+def test_world_result_arrays_equal_copied(epi):
+    """epi_world_result_buffers: results read in place from the handle's own arrays are the ones the copying
+    path returns."""
+    from epidemicsimulator_amd import synth
+    countries, xy = synth.make_countries(30, 8)
+    conn = synth.gravity_dense(countries, xy)
+    B = 7
+    wa, _, rng = _world_pair(epi, countries, conn, batch=B)
+    wb, _, _ = _world_pair(epi, countries, conn, batch=B)
+    st_b, rw_b = wb.result_arrays()
+    assert st_b.shape == (B, 30) and rw_b.shape == (B, 30)
+    for step in range(5):
+        acts = rng.integers(0, 8, (B, 30)); gauss = rng.normal(size=(B, 30))
+        st_a, rw_a = wa.step_arrays(acts, gauss, 120)
+        if step == 3:     # caller-owned arrays still work on the same world
+            got_s, got_r = wb.step_arrays(acts, gauss, 120)
+        else:
+            got_s, got_r = wb.step_arrays(acts, gauss, 120, st_b, rw_b)
+            assert got_s is st_b
+        np.testing.assert_array_equal(got_s, st_a)
+        np.testing.assert_array_equal(got_r, rw_a)
+    del st_b, rw_b, got_s, got_r
+    wa.close(); wb.close()
+
+
 def test_world_step_one_and_greedy_follow_reference_streams(epi):
     """stepOne / stepOneGreedy with the JVM-compatible agent and env streams (EvalDeterminismSpec.scala
     inputs: base tMax=120, beta 0.26, noise 0.02), checked against the oracle's WorldToy."""
