@@ -235,13 +235,13 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
 }
 
 // ---------------------------------------------------------------------------------------------
-// Sparse episode kernel for graphs too wide for the dense kernel.  One workgroup of 512 threads =
-// one episode; compartments live in HBM and are streamed once per phase; the two inflow
+// Sparse episode kernel for graphs too wide for the dense kernel.  One workgroup of kCsrThreads
+// threads = one episode; compartments live in HBM and are streamed once per step; the two inflow
 // accumulators movedS/movedI for all n patches live in LDS (8 bytes per patch).
 //
-// Mobility (WorldToy.scala:106-126): ONE LANE owns one row.  Rows are stored in blocks of 64 in a
-// slot-major (ELL) layout -- slot k of the 64 rows of a block is contiguous -- so that the 64 lanes
-// of a wave read their k-th weights with one coalesced load.  Every lane runs the same
+// Mobility (WorldToy.scala:106-126): ONE LANE owns one row.  Rows (sorted by length) are stored in
+// blocks of 64 in a slot-major (ELL) layout -- slot k of the 64 rows of a block is contiguous -- so that
+// the 64 lanes of a wave read their k-th weights with one coalesced load.  Every lane runs the same
 // largest-remainder split as the dense kernel on its own short row, entirely in its registers:
 // high words of the fractions as keys, the threshold K = the rem-th largest key taken from a copy
 // sorted by a sorting network, ties in the high word finished exactly on the full fractions in
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
 // fractions up to a rounding error far below 1, and every fraction is below 1), so the units go
 // to stored entries only; the kernel checks this and reports EPI_ERR_UNSUPPORTED otherwise.
 // ---------------------------------------------------------------------------------------------
-constexpr int kCsrThreads = 768;  // 8 waves: room for a whole row of keys per lane without spilling
+constexpr int kCsrThreads = 768;  // 12 waves, 3 per SIMD: ~170 registers per lane for the keys of two compartments
 
 // Slots are read in groups of kSlotGroup: a group is skipped when the block has no such slots, and all
 // loads of the groups that are read are issued before the first one is consumed.  Every block's slot
