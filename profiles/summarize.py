@@ -5,7 +5,8 @@
 Writes <out>.json (read by bench.py for the `traffic` field) and <out>.md, and copies the kernel-stats CSV.
 HBM traffic follows the gfx950 rule for FETCH_SIZE (reported in KiB and exactly half of the bytes of a
 coalesced read; confirmed for this kernel's 8 B/lane pattern with tools/calib_fetch.hip: a 4 GiB read reports
-2,097,155 KiB); WRITE_SIZE (KiB) is taken as is."""
+2,097,155 KiB); WRITE_SIZE (KiB) is taken as is (the same tool: 4 GiB written with 4 B or 8 B per lane reports
+4,194,304 KiB)."""
 import collections
 import csv
 import glob
