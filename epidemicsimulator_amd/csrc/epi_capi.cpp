@@ -880,14 +880,18 @@ EPI_API int32_t epi_grid_destroy(epi_grid* g) {
     if (g->stats.p) {
         unsigned long long h[64];
         if (hipMemcpy(h, g->stats.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < 2; ++k) {  // threshold-search statistics of the dense kernel
                 const unsigned long long* s = h + 32 * k;
+                if (s[0] == 0) continue;
                 fprintf(stderr, "[epi stats %s] rows %llu probes %llu (%.2f/row) cold %llu ties %llu hist:", k ? "I" : "S", s[0], s[1],
-                        s[0] ? (double)s[1] / (double)s[0] : 0.0, s[2], s[3]);
+                        (double)s[1] / (double)s[0], s[2], s[3]);
                 for (int b = 0; b < 28; ++b) fprintf(stderr, " %llu", s[4 + b]);
                 fprintf(stderr, "\n");
             }
-            fprintf(stderr, "[epi cycles] pass1 %llu select %llu pass2 %llu | A %llu barA %llu B %llu barB %llu C %llu\n", h[48], h[49], h[50], h[51], h[52], h[53], h[54], h[55]);
+            // phase timers of the sparse kernel (builds with -DEPI_CSR_TIMERS); they share slots with the histogram above
+            if (h[0] == 0 && h[32] == 0 && (h[48] | h[51] | h[53]))
+                fprintf(stderr, "[epi cycles] pass1 %llu select %llu pass2 %llu | local+apply %llu barrier %llu mobility %llu barrier %llu\n",
+                        h[48], h[49], h[50], h[51], h[52], h[53], h[54]);
         }
     }
     delete g;
