@@ -18,12 +18,12 @@ __device__ __forceinline__ void keep_loaded(T& x) {
     asm volatile("" : "+v"(x));
 }
 
-// WorldToy.scala:115: min(X.toLong, floor(X * sumW + 1e-9).toLong).toInt for X >= 0, sumW >= 0.
+// WorldToy.scala:115: min(X.toLong, floor(X * sumW + 1e-9).toLong).toInt for X >= 0 and finite sumW >= 0.
+// e is a non-negative integer-valued double: when it reaches X the minimum is X, otherwise it is below
+// 2^31 and converts exactly (no 64-bit conversion needed).
 __device__ __forceinline__ int32_t export_count(int32_t X, double sumW) {
     const double e = floor((double)X * sumW + 1e-9);
-    const long long l = (e >= 9223372036854775807.0) ? 0x7fffffffffffffffLL : (long long)e;
-    const long long m = (long long)X < l ? (long long)X : l;
-    return (int32_t)m;
+    return e >= (double)X ? X : (int32_t)e;
 }
 
 __device__ __forceinline__ void record_error(int* sh_err, int code, int node, int t) {
