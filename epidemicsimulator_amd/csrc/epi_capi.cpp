@@ -196,7 +196,7 @@ struct GraphTables {
     // sparse mode (n > kMaxDenseN): CSR arrays on the device, raw weights on the host
     bool sparse = false;
     int max_deg = 0, lane_deg = 0;
-    DevBuf d_rowptr, d_col, d_qval, d_ell, d_ell_rows, d_ell_pos, d_long_rows, d_long_q, d_long_col;
+    DevBuf d_rowptr, d_col, d_qval, d_ell, d_ell_rows, d_ell_pos, d_long_rows, d_long_off, d_long_q, d_long_col;
     std::vector<int32_t> h_long_rows;     // rows longer than kLaneSlots
     std::vector<int32_t> h_slots, h_off;  // ELL block tables
     std::vector<int32_t> h_pos;           // row -> position in the lane layout (block * 64 + lane), -1 for long rows
@@ -313,13 +313,21 @@ struct GraphTables {
             }
         }
         const size_t nl = h_long_rows.size();
-        std::vector<double> lq((nl ? nl : 1) * 64, 0.0);
-        std::vector<int32_t> lc((nl ? nl : 1) * 64, -1), lr(h_long_rows);
+        std::vector<int32_t> lr(h_long_rows), lo(nl ? nl : 1, 0);
+        size_t long_elems = 0;
+        for (size_t o = 0; o < nl; ++o) {
+            const int i = h_long_rows[o];
+            lo[o] = (int32_t)long_elems;
+            long_elems += (size_t)64 * dense_slots_for(h_rowptr[i + 1] - h_rowptr[i]);
+        }
+        std::vector<double> lq(long_elems ? long_elems : 64, 0.0);
+        std::vector<int32_t> lc(long_elems ? long_elems : 64, -1);
         for (size_t o = 0; o < nl; ++o) {
             const int i = h_long_rows[o], rs = h_rowptr[i], deg = h_rowptr[i + 1] - rs;
-            for (int k = 0; k < deg; ++k) { lq[o * 64 + k] = hq[rs + k]; lc[o * 64 + k] = h_col[rs + k]; }
+            for (int k = 0; k < deg; ++k) { lq[(size_t)lo[o] + k] = hq[rs + k]; lc[(size_t)lo[o] + k] = h_col[rs + k]; }
         }
         if (lr.empty()) lr.push_back(0);
+        HIP_TRY(d_long_off.upload(lo));
         HIP_TRY(d_long_rows.upload(lr));
         HIP_TRY(d_long_q.upload(lq));
         HIP_TRY(d_long_col.upload(lc));
@@ -352,7 +360,7 @@ struct GraphTables {
             ea.seed_block = -1;
             ea.max_deg = lane_deg;
             ea.n_long = (int)h_long_rows.size();
-            ea.long_rows = d_long_rows.as<int32_t>(); ea.long_q = d_long_q.as<double>(); ea.long_col = d_long_col.as<int32_t>();
+            ea.long_rows = d_long_rows.as<int32_t>(); ea.long_off = d_long_off.as<int32_t>(); ea.long_q = d_long_q.as<double>(); ea.long_col = d_long_col.as<int32_t>();
         } else {
             ea.q = q.as<double>(); ea.qtop = qtop.as<double>();
             ea.rowptr = nullptr;
@@ -724,15 +732,15 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
         const int rs = G->graph.h_rowptr[d->seed_idx], deg = G->graph.h_rowptr[d->seed_idx + 1] - rs;
         const int nt = d->n_travel > 0 ? d->n_travel : 1;
         const bool seed_long = deg > kLaneSlots;
-        // a long seed row is read by one wave as 64 padded slots; otherwise the whole 64-row block of the
+        // a long seed row is read by one wave as whole groups of 64 padded slots; otherwise the whole 64-row block of the
         // seed row is copied once per travel scale (kLaneSlots slots each) with that one row replaced
-        const int slots = seed_long ? 64 : kLaneSlots;
+        const int slots = seed_long ? 64 * dense_slots_for(deg) : kLaneSlots;
         const int spos = G->graph.h_pos[d->seed_idx];
         const int sb = seed_long ? 0 : spos / 64, sl = seed_long ? 0 : spos % 64;
         G->seed_block = seed_long ? -1 : sb;
         G->seed_long = seed_long ? 1 : 0;
         std::vector<double> hq((size_t)nt * slots * (seed_long ? 1 : 64), 0.0), hs((size_t)nt, 0.0), row((size_t)(deg > 0 ? deg : 1));
-        std::vector<double> qrow((size_t)64, 0.0);
+        std::vector<double> qrow((size_t)std::max(64, slots), 0.0);
         for (int k = 0; k < d->n_travel; ++k) {
             if (!std::isfinite(d->travel[k]) || d->travel[k] < 0.0) return fail(EPI_ERR_BAD_ARGUMENT, "grid: travel scale %d = %g", k, d->travel[k]);
             double s = 0.0;
@@ -750,7 +758,7 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
             rc = GraphTables::normalise_sparse_row(row.data(), G->graph.h_col.data() + rs, deg, d->seed_idx, qrow.data(), &hs[k]);
             if (rc) return rc;
             if (seed_long) {
-                std::copy(qrow.begin(), qrow.end(), hq.begin() + (size_t)k * 64);
+                std::copy(qrow.begin(), qrow.begin() + slots, hq.begin() + (size_t)k * slots);
             } else {
                 double* blk = &hq[(size_t)k * slots * 64];
                 const int bs = G->graph.h_slots[sb];

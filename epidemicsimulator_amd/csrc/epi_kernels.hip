@@ -421,6 +421,28 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
     EPI_TM(__builtin_amdgcn_s_waitcnt(0); { const long long c1 = clock64(); tm[2] += c1 - c0; })
 }
 
+// One row longer than a lane holds (up to 64 * R stored weights): the whole wave splits it with the dense
+// kernel's routine, S then I, and scatters through the row's column list.
+template <int R>
+__device__ __noinline__ void long_row(int32_t ES, int32_t EI, int deg, int row, const double* __restrict__ qrow,
+                                      const int32_t* __restrict__ crow, int lane, uint32_t* sh_movS, uint32_t* sh_movI) {
+#pragma nounroll
+    for (int comp = 0; comp < 2; ++comp) {
+        const int32_t E = comp ? EI : ES;
+        if (E <= 0) continue;
+        uint32_t acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0u;
+        apportion_row<R>(E, deg, -1, qrow, acc, lane, nullptr);
+        uint32_t* sh_mov = comp ? sh_movI : sh_movS;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int col = crow[r * 64 + lane];
+            if (col >= 0 && col != row && acc[r]) atomicAdd(&sh_mov[col], acc[r]);
+        }
+    }
+}
+
 template <int DMAX>
 __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeArgs a) {
     extern __shared__ __align__(16) unsigned char sh_raw[];
@@ -645,24 +667,20 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                     }
                 } else {
                     // a row longer than kLaneSlots: one wave with the dense kernel's routine on the compact
-                    // row (64 slots, zero padded), scattered through the row's column list
+                    // row (whole groups of 64 slots, zero padded), scattered through the row's column list
                     const int o = item - nblocks;
                     const int row = a.long_rows[o];
                     const int32_t ESl = __builtin_amdgcn_readfirstlane(expS[row]);
                     const int32_t EIl = __builtin_amdgcn_readfirstlane(expI[row]);
                     if ((ESl | EIl) != 0) {
                         const int deg = a.rowptr[row + 1] - a.rowptr[row];
+                        const int32_t* __restrict__ crow = a.long_col + a.long_off[o];
                         const double* __restrict__ qrow = (row == a.seed_idx && a.qval_seed && a.seed_long)
                                                               ? a.qval_seed + (size_t)ti * a.seed_deg
-                                                              : a.long_q + (size_t)o * 64;
-                        const int col = a.long_col[(size_t)o * 64 + lane];
-#pragma nounroll
-                        for (int comp = 0; comp < 2; ++comp) {
-                            const int32_t E = comp ? EIl : ESl;
-                            uint32_t acc[1] = {0u};
-                            if (E > 0) apportion_row<1>(E, deg, -1, qrow, acc, lane, nullptr);
-                            if (col >= 0 && col != row && acc[0]) atomicAdd(comp ? &sh_movI[col] : &sh_movS[col], acc[0]);
-                        }
+                                                              : a.long_q + a.long_off[o];
+                        if (deg <= 64) long_row<1>(ESl, EIl, deg, row, qrow, crow, lane, sh_movS, sh_movI);
+                        else if (deg <= 128) long_row<2>(ESl, EIl, deg, row, qrow, crow, lane, sh_movS, sh_movI);
+                        else long_row<4>(ESl, EIl, deg, row, qrow, crow, lane, sh_movS, sh_movI);
                     }
                 }
                 item = next;

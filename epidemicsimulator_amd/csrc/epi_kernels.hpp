@@ -11,7 +11,7 @@ namespace epi {
 constexpr int kMaxDenseR = 16;               // register slots per lane in the dense row kernel
 constexpr int kMaxDenseN = kMaxDenseR * 64;  // widest dense row held in one wave's registers
 constexpr size_t kMaxLdsBytes = 160 * 1024;  // LDS of one CU: bounds the patches of a sparse world
-constexpr int kMaxSparseDegree = 64;          // longest stored row the sparse kernel apportions
+constexpr int kMaxSparseDegree = 256;         // longest stored row the sparse kernel apportions (one wave, 4 slots per lane)
 constexpr int kLaneSlots = 32;                // longest row a single lane keeps in registers
 constexpr int kSlotGroup = 8;                 // ELL blocks are stored in whole groups of this many slots
 size_t csr_lds_bytes(int n);
@@ -56,8 +56,9 @@ struct EpisodeArgs {
     int seed_long;            // the seed row is one of the long rows below
     int n_long;               // rows longer than kLaneSlots: compact copies, 64 slots each
     const int32_t* long_rows; // [n_long]
-    const double* long_q;     // [n_long][64]
-    const int32_t* long_col;  // [n_long][64], -1 = padding
+    const int32_t* long_off;  // [n_long] first element of the row's compact copy in long_q / long_col
+    const double* long_q;     // compact copies: a row of deg weights occupies 64 * dense_slots_for(deg) elements
+    const int32_t* long_col;  // same shape, -1 = padding
     int32_t* exports;        // [4][count][npad] scratch of the sparse kernel: exportS / exportI by patch, then the
                              // same two by position in the lane layout
     const double* qtop;      // [n][kTopWeights] each row's largest normalised weights, descending (or NULL)
