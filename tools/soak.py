@@ -30,7 +30,20 @@ def main():
         wl = synth.small_workload(8, 1, 2, steps, seed=seed)
         wl["countries"], wl["profiles"] = countries, countries
         if sparse:
-            wl["conn"] = synth.gravity_csr(countries, xy, seed, mean_degree=float(rng.choice([2.0, 5.0, 9.0, 14.0, 20.0, 31.0])))
+            rp, col, val = synth.gravity_csr(countries, xy, seed, mean_degree=float(rng.choice([2.0, 5.0, 9.0, 14.0, 20.0, 31.0])))
+            if rng.random() < 0.4:   # a few hub rows of up to 256 stored weights
+                rows = [list(zip(col[rp[i]:rp[i + 1]], val[rp[i]:rp[i + 1]])) for i in range(n)]
+                for i in rng.choice(n, size=int(rng.integers(1, 6)), replace=False):
+                    deg = int(rng.integers(33, 257))
+                    nb = np.sort(rng.choice(np.delete(np.arange(n), i), size=deg, replace=False))
+                    w = rng.random(deg) + 0.01
+                    w *= 0.12 / w.sum()
+                    rows[i] = list(zip(nb.tolist(), w.tolist()))
+                rp = np.zeros(n + 1, dtype=np.int32)
+                rp[1:] = np.cumsum([len(r) for r in rows])
+                col = np.array([c for r in rows for c, _ in r], dtype=np.int32)
+                val = np.array([v for r in rows for _, v in r], dtype=np.float64)
+            wl["conn"] = (rp, col, val)
         elif n > 1:
             wl["conn"] = synth.gravity_dense(countries, xy)
         else:
