@@ -189,6 +189,13 @@ int32_t densify(int n, const double* conn, const int32_t* rowptr, const int32_t*
 }
 
 // Device-resident tables shared by the sweep and the world API.
+// Elements a long row's compact copy occupies: whole groups of 64 (1, 2 or 4 groups for the register
+// routines up to 256 weights, as many as needed for the streamed rows above that).
+static size_t long_row_slots(int deg) {
+    if (deg <= kMaxSparseDegree) return (size_t)64 * dense_slots_for(deg);
+    return ((size_t)deg + 63) / 64 * 64;
+}
+
 struct GraphTables {
     int n = 0, npad = 0;
     DevBuf q, sumw, pop, qtop;
@@ -256,8 +263,6 @@ struct GraphTables {
         }
         max_deg = 0;
         for (int i = 0; i < n; ++i) max_deg = std::max(max_deg, h_rowptr[i + 1] - h_rowptr[i]);
-        if (max_deg > kMaxSparseDegree)
-            return fail(EPI_ERR_UNSUPPORTED, "a row stores %d weights: worlds of more than %d patches support at most %d per row", max_deg, kMaxDenseN, kMaxSparseDegree);
         std::vector<double> hq(h_val.size() ? h_val.size() : 1, 0.0), hs((size_t)npad, 0.0);
         for (int i = 0; i < n; ++i) {
             const int rs = h_rowptr[i], deg = h_rowptr[i + 1] - rs;
@@ -318,7 +323,7 @@ struct GraphTables {
         for (size_t o = 0; o < nl; ++o) {
             const int i = h_long_rows[o];
             lo[o] = (int32_t)long_elems;
-            long_elems += (size_t)64 * dense_slots_for(h_rowptr[i + 1] - h_rowptr[i]);
+            long_elems += long_row_slots(h_rowptr[i + 1] - h_rowptr[i]);
         }
         std::vector<double> lq(long_elems ? long_elems : 64, 0.0);
         std::vector<int32_t> lc(long_elems ? long_elems : 64, -1);
@@ -734,7 +739,7 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
         const bool seed_long = deg > kLaneSlots;
         // a long seed row is read by one wave as whole groups of 64 padded slots; otherwise the whole 64-row block of the
         // seed row is copied once per travel scale (kLaneSlots slots each) with that one row replaced
-        const int slots = seed_long ? 64 * dense_slots_for(deg) : kLaneSlots;
+        const int slots = seed_long ? (int)long_row_slots(deg) : kLaneSlots;
         const int spos = G->graph.h_pos[d->seed_idx];
         const int sb = seed_long ? 0 : spos / 64, sl = seed_long ? 0 : spos % 64;
         G->seed_block = seed_long ? -1 : sb;

@@ -421,6 +421,126 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
     EPI_TM(__builtin_amdgcn_s_waitcnt(0); { const long long c1 = clock64(); tm[2] += c1 - c0; })
 }
 
+// A row too long for the register routines (more than 256 stored weights, e.g. a dense graph given for a
+// world of more than 1,024 countries): one wave streams the compact row once per counting probe and forms
+// the keys again each time.  Same selection as everywhere else -- the rem largest fractions, ties in the
+// high word finished on the low word and then in column order -- only slower: this path exists so that no
+// finite non-negative graph is refused for its row lengths.
+__device__ __noinline__ void wide_row(int32_t ES, int32_t EI, int deg, int row, const double* __restrict__ qrow,
+                                      const int32_t* __restrict__ crow, int lane, uint32_t* sh_movS, uint32_t* sh_movI,
+                                      int* sh_err, int t) {
+    const int chunks = (deg + 63) >> 6;
+#pragma nounroll
+    for (int comp = 0; comp < 2; ++comp) {
+        const int32_t E = comp ? EI : ES;
+        if (E <= 0) continue;
+        uint32_t* sh_mov = comp ? sh_movI : sh_movS;
+        const double Ed = (double)E;
+        // pass 1: whole units, largest key, number of positive fractions
+        uint32_t bsum = 0u, kmax = 0u, pos = 0u;
+        for (int ch = 0; ch < chunks; ++ch) {
+            const int j = ch * 64 + lane;
+            const double raw = qrow[j] * Ed;  // padding slots hold weight 0
+            const double fr = frac_of(raw);
+            const uint32_t b = (uint32_t)(int32_t)raw;
+            const int col = crow[j];
+            if (b != 0u && col >= 0 && col != row) atomicAdd(&sh_mov[col], b);
+            bsum += b;
+            kmax = max(kmax, (uint32_t)__double2hiint(fr));
+            pos += (fr > 0.0);
+        }
+        const int32_t rem = (int32_t)((uint32_t)E - wave_sum(bsum));
+        if (rem <= 0) continue;
+        if (rem > (int32_t)wave_sum(pos)) {
+            if (lane == 0) record_error(sh_err, EPI_ERR_UNSUPPORTED, row, t);
+            continue;
+        }
+        // threshold search on the high words: #{key >= lo} = clo > rem > chi = #{key >= hi}
+        uint32_t lo = 0u, hi = wave_max(kmax) + 1u, K = 0u;
+        int clo = chunks * 64, chi = 0, it = 0;
+        bool found = false;
+        while (hi - lo > 1u) {
+            uint32_t mid;
+            if (it & 1) {
+                mid = lo + ((hi - lo) >> 1);
+            } else {
+                const float f = ((float)(clo - rem) + 0.5f) * __builtin_amdgcn_rcpf((float)(clo - chi + 1));
+                const double vlo = from_hi_word(lo), vhi = from_hi_word(hi);
+                mid = (uint32_t)__double2hiint(vlo + (vhi - vlo) * (double)f);
+            }
+            mid = max(mid, lo + 1u);
+            mid = min(mid, hi - 1u);
+            mid = (uint32_t)__builtin_amdgcn_readfirstlane((int)mid);
+            uint32_t cu = 0u;
+            for (int ch = 0; ch < chunks; ++ch)
+                cu += ((uint32_t)__double2hiint(frac_of(qrow[ch * 64 + lane] * Ed)) >= mid);
+            const int c = (int)wave_sum(cu);
+            ++it;
+            if (c == rem) { found = true; K = mid; break; }
+            if (c > rem) { lo = mid; clo = c; }
+            else { hi = mid; chi = c; }
+        }
+        // tie in the high word `lo`: m = rem - chi members by (low word descending, column ascending)
+        unsigned long long Llo = 0ull;
+        int m2 = 0;
+        if (!found) {
+            K = lo;
+            const int m = rem - chi;
+            uint32_t mn = 0xffffffffu, mx = 0u;
+            for (int ch = 0; ch < chunks; ++ch) {
+                const int j = ch * 64 + lane;
+                const double fr = frac_of(qrow[j] * Ed);
+                if (j < deg && (uint32_t)__double2hiint(fr) == K) {
+                    mn = min(mn, (uint32_t)__double2loint(fr));
+                    mx = max(mx, (uint32_t)__double2loint(fr));
+                }
+            }
+            Llo = wave_min(mn);
+            unsigned long long Lhi = (unsigned long long)wave_max(mx) + 1ull;
+            int c_hi = 0;
+            bool exact = false;
+            while (Lhi - Llo > 1ull) {
+                const unsigned long long lmid = Llo + ((Lhi - Llo) >> 1);
+                uint32_t cu = 0u;
+                for (int ch = 0; ch < chunks; ++ch) {
+                    const int j = ch * 64 + lane;
+                    const double fr = frac_of(qrow[j] * Ed);
+                    cu += (j < deg && (uint32_t)__double2hiint(fr) == K && (unsigned long long)(uint32_t)__double2loint(fr) >= lmid);
+                }
+                const int c = (int)wave_sum(cu);
+                if (c == m) { Llo = lmid; exact = true; break; }
+                if (c > m) Llo = lmid;
+                else { Lhi = lmid; c_hi = c; }
+            }
+            // exact: members with low word >= Llo are exactly m.  Otherwise fractions identical to the pivot
+            // (low word == Llo) share the last m2 units in ascending column order.
+            m2 = exact ? 0x7fffffff : m - c_hi;
+        }
+        // final pass: one unit for every selected column, in column order for the identical fractions
+        int run = 0;
+        for (int ch = 0; ch < chunks; ++ch) {
+            const int j = ch * 64 + lane;
+            const double fr = frac_of(qrow[j] * Ed);
+            const uint32_t key = (uint32_t)__double2hiint(fr);
+            bool take;
+            if (found) {
+                take = key >= K;
+            } else {
+                const bool mem = j < deg && key == K;
+                const unsigned long long l = (unsigned long long)(uint32_t)__double2loint(fr);
+                const bool above = mem && l > Llo;
+                const bool eq = mem && l == Llo;
+                const unsigned long long mask = __ballot(eq);
+                const int pre = (int)lanes_below(mask);
+                take = key > K || above || (eq && run + pre < m2);
+                run += __popcll(mask);
+            }
+            const int col = crow[j];
+            if (take && j < deg && col >= 0 && col != row) atomicAdd(&sh_mov[col], 1u);
+        }
+    }
+}
+
 // One row longer than a lane holds (up to 64 * R stored weights): the whole wave splits it with the dense
 // kernel's routine, S then I, and scatters through the row's column list.
 template <int R>
@@ -680,7 +800,8 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                                                               : a.long_q + a.long_off[o];
                         if (deg <= 64) long_row<1>(ESl, EIl, deg, row, qrow, crow, lane, sh_movS, sh_movI);
                         else if (deg <= 128) long_row<2>(ESl, EIl, deg, row, qrow, crow, lane, sh_movS, sh_movI);
-                        else long_row<4>(ESl, EIl, deg, row, qrow, crow, lane, sh_movS, sh_movI);
+                        else if (deg <= 256) long_row<4>(ESl, EIl, deg, row, qrow, crow, lane, sh_movS, sh_movI);
+                        else wide_row(ESl, EIl, deg, row, qrow, crow, lane, sh_movS, sh_movI, sh_err, t);
                     }
                 }
                 item = next;

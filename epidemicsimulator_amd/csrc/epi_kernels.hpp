@@ -11,7 +11,8 @@ namespace epi {
 constexpr int kMaxDenseR = 16;               // register slots per lane in the dense row kernel
 constexpr int kMaxDenseN = kMaxDenseR * 64;  // widest dense row held in one wave's registers
 constexpr size_t kMaxLdsBytes = 160 * 1024;  // LDS of one CU: bounds the patches of a sparse world
-constexpr int kMaxSparseDegree = 256;         // longest stored row the sparse kernel apportions (one wave, 4 slots per lane)
+constexpr int kMaxSparseDegree = 256;         // longest stored row apportioned in registers (one wave, 4 slots per lane);
+                                              // longer rows are streamed from memory by one wave
 constexpr int kLaneSlots = 32;                // longest row a single lane keeps in registers
 constexpr int kSlotGroup = 8;                 // ELL blocks are stored in whole groups of this many slots
 size_t csr_lds_bytes(int n);

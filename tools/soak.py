@@ -31,10 +31,10 @@ def main():
         wl["countries"], wl["profiles"] = countries, countries
         if sparse:
             rp, col, val = synth.gravity_csr(countries, xy, seed, mean_degree=float(rng.choice([2.0, 5.0, 9.0, 14.0, 20.0, 31.0])))
-            if rng.random() < 0.4:   # a few hub rows of up to 256 stored weights
+            if rng.random() < 0.4:   # a few hub rows: mostly up to 256 stored weights, some streamed ones above that
                 rows = [list(zip(col[rp[i]:rp[i + 1]], val[rp[i]:rp[i + 1]])) for i in range(n)]
                 for i in rng.choice(n, size=int(rng.integers(1, 6)), replace=False):
-                    deg = int(rng.integers(33, 257))
+                    deg = int(rng.integers(33, 257)) if rng.random() < 0.8 else int(rng.integers(257, n))
                     nb = np.sort(rng.choice(np.delete(np.arange(n), i), size=deg, replace=False))
                     w = rng.random(deg) + 0.01
                     w *= 0.12 / w.sum()
