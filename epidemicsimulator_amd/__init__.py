@@ -346,6 +346,199 @@ def mlp_greedy(states: Sequence[State], weights, clip_q: float = 10.0):
 
 
 # ------------------------------------------------------------------------------------------------
+# DDQNAgent.scala / MLP.scala / ReplayBuffer.scala: learners on the device
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class Transition:  # ReplayBuffer.scala:8
+    s: State
+    a: int
+    r: float
+    s2: State
+    done: bool
+
+
+class Agents:
+    """A set of independent DDQN learners (one per country, WorldToy.scala:46-65) held by one device handle:
+    replay buffers, online and target networks, DDQNAgent.learn for any subset of them in one set of launches."""
+
+    def __init__(self, hps: Sequence[HyperParams], max_grad_accum: int = 4, device: int = 0):
+        self.hps = list(hps)
+        self.n = len(self.hps)
+        arr = (_capi.LearnHyper * self.n)(*[
+            _capi.LearnHyper(h.gamma, h.lr, h.clip_q, h.grad_clip, h.ema_alpha, h.hidden, h.replay_capacity,
+                             h.target_update_every, h.batch_size * max(1, max_grad_accum)) for h in self.hps])
+        h = lib().epi_agents_create(C.c_int32(self.n), arr, C.c_int32(device))
+        if not h:
+            raise EpiError(_capi.EPI_ERR_BAD_ARGUMENT, _capi.last_error())
+        self._h = C.c_void_p(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().epi_agents_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _ids(ids, count):
+        return (None, count) if ids is None else (ptr(i32(ids), C.c_int32), len(ids))
+
+    def observe(self, transitions: Sequence[Transition], ids: Optional[Sequence[int]] = None) -> None:
+        """DDQNAgent.observe (:34) for one transition per listed agent (default: agents 0..len-1)."""
+        k = len(transitions)
+        idp, _ = Agents._ids(ids, k)
+        s = (_capi.CState * k)(*[t.s._c() for t in transitions])
+        s2 = (_capi.CState * k)(*[t.s2._c() for t in transitions])
+        a = i32([t.a for t in transitions]); r = f64([t.r for t in transitions])
+        d = np.ascontiguousarray([1 if t.done else 0 for t in transitions], dtype=np.uint8)
+        check(lib().epi_agents_observe(self._h, idp, C.c_int32(k), s, ptr(a, C.c_int32), ptr(r, C.c_double), s2,
+                                       ptr(d, C.c_uint8)))
+
+    def replay_size(self) -> np.ndarray:
+        out = np.zeros(self.n, dtype=np.int32)
+        check(lib().epi_agents_replay_size(self._h, ptr(out, C.c_int32)))
+        return out
+
+    def sample(self, agent: int, n: int) -> np.ndarray:
+        """Buffer positions ReplayBuffer.sample(n) returns (ReplayBuffer.scala:21-22); advances the shuffle stream."""
+        out = np.zeros(max(n, 1), dtype=np.int32); k = C.c_int32(0)
+        check(lib().epi_agents_sample(self._h, C.c_int32(agent), C.c_int32(n), ptr(out, C.c_int32), C.byref(k)))
+        return out[:k.value]
+
+    def learn(self, steps: Sequence[int], batch: Optional[Sequence[int]] = None, grad_accum=4,
+              ids: Optional[Sequence[int]] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """DDQNAgent.learn(batch, gradAccumSteps) (:51-65) for the listed agents; steps[k] is each agent's act()
+        counter.  Returns (loss, emaLossNow) per listed agent."""
+        idp, k = Agents._ids(ids, len(steps))
+        who = list(range(k)) if ids is None else list(ids)
+        b = i32([self.hps[i].batch_size for i in who] if batch is None else batch)
+        ga = i32([grad_accum] * k if np.isscalar(grad_accum) else grad_accum)
+        st = np.ascontiguousarray(steps, dtype=np.int64)
+        loss = np.zeros(k); ema = np.zeros(k)
+        check(lib().epi_agents_learn(self._h, idp, C.c_int32(k), ptr(b, C.c_int32), ptr(ga, C.c_int32),
+                                     st.ctypes.data_as(C.POINTER(C.c_int64)), ptr(loss, C.c_double), ptr(ema, C.c_double)))
+        return loss, ema
+
+    def q_values(self, states: Sequence[State], ids: Optional[Sequence[int]] = None, target: bool = False):
+        """(q[k][8], first argmax[k]) of one state per listed agent (DDQNAgent.qValues / actGreedy, :22-23,70)."""
+        k = len(states)
+        idp, _ = Agents._ids(ids, k)
+        arr = (_capi.CState * k)(*[s._c() for s in states])
+        q = np.zeros((k, 8)); g = np.zeros(k, dtype=np.int32)
+        check(lib().epi_agents_q_values(self._h, idp, C.c_int32(k), arr, C.c_int32(int(target)), ptr(q, C.c_double),
+                                        ptr(g, C.c_int32)))
+        return q, g
+
+    def weights(self, agent: int, target: bool = False):
+        """[W1[h][7], b1[h], W2[h][h], b2[h], W3[8][h], b3[8]] of one agent's online (or target) network."""
+        h = self.hps[agent].hidden
+        W = [np.zeros((h, 7)), np.zeros(h), np.zeros((h, h)), np.zeros(h), np.zeros((8, h)), np.zeros(8)]
+        check(lib().epi_agents_get_weights(self._h, C.c_int32(agent), C.c_int32(int(target)), *[ptr(w, C.c_double) for w in W]))
+        return W
+
+    def set_weights(self, agent: int, W, target: bool = False) -> None:
+        W = [f64(w) for w in W]
+        check(lib().epi_agents_set_weights(self._h, C.c_int32(agent), C.c_int32(int(target)), *[ptr(w, C.c_double) for w in W]))
+
+    def set_timing(self, on: bool):
+        check(lib().epi_agents_set_timing(self._h, C.c_int32(int(on))))
+
+    def kernel_time(self):
+        """(device ms of the learn launches, learn calls, samples trained on) since timing was switched on."""
+        ms = C.c_double(0); k = C.c_int64(0); n = C.c_int64(0)
+        check(lib().epi_agents_kernel_time(self._h, C.byref(ms), C.byref(k), C.byref(n)))
+        return ms.value, k.value, n.value
+
+
+class DDQNAgent:
+    """DDQNAgent.scala:6-70 for one agent: its own epsilon stream (Random(9)) on the host, networks and learn
+    step on the device.  `pool`/`index` place it in a shared Agents handle (WorldToy does that for its nodes)."""
+
+    def __init__(self, hp: HyperParams, state_size: int = 7, action_size: int = 8, pool: Optional[Agents] = None,
+                 index: int = 0, device: int = 0):
+        assert state_size == 7 and action_size == 8, "State.features has 7 entries and Action 8 values"
+        self.hp = hp
+        self._pool = pool if pool is not None else Agents([hp], device=device)
+        self._k = index if pool is not None else 0
+        self.steps = 0
+        self._rnd = _JavaRandom(9)
+
+    @property
+    def epsilon_now(self) -> float:  # :16-19,67
+        frac = min(1.0, float(self.steps) / max(1, self.hp.epsilon_decay_steps))
+        return self.hp.epsilon_start + (self.hp.epsilon_end - self.hp.epsilon_start) * frac
+
+    def act_greedy(self, s: State) -> int:  # :22-23
+        return int(self._pool.q_values([s], [self._k])[1][0])
+
+    def act_with_epsilon(self, s: State, eps: float, count_step: bool = False) -> int:  # :26-30
+        if count_step:
+            self.steps += 1
+        if self._rnd.next_double() < eps:
+            return self._rnd.next_int(8)
+        return self.act_greedy(s)
+
+    def explores(self, eps: float, count_step: bool = False) -> int:
+        """The random branch of act_with_epsilon without the network: 0..7, or -1 where argmax Q is taken."""
+        if count_step:
+            self.steps += 1
+        return self._rnd.next_int(8) if self._rnd.next_double() < eps else -1
+
+    def act(self, s: State) -> int:  # :32 -- epsilon is an argument: read before the call counts the step
+        return self.act_with_epsilon(s, self.epsilon_now, count_step=True)
+
+    def observe(self, tr: Transition) -> None:  # :34
+        self._pool.observe([tr], [self._k])
+
+    def learn(self, batch: int, grad_accum_steps: int = 4) -> float:  # :51-65
+        loss, ema = self._pool.learn([self.steps], [batch], grad_accum_steps, [self._k])
+        self._ema = float(ema[0])
+        return float(loss[0])
+
+    @property
+    def ema_loss_now(self) -> float:  # :68
+        return getattr(self, "_ema", 0.0)
+
+    @property
+    def replay_size(self) -> int:  # :69
+        return int(self._pool.replay_size()[self._k])
+
+    def q_values(self, s: State) -> np.ndarray:  # :70
+        return self._pool.q_values([s], [self._k])[0][0]
+
+
+class _JavaRandom:
+    """java.util.Random on the host side of the boundary (48-bit LCG, JDK javadoc), for the agent's own draws."""
+
+    def __init__(self, seed: int):
+        self.state = (seed ^ 0x5DEECE66D) & ((1 << 48) - 1)
+
+    def _next(self, bits: int) -> int:
+        self.state = (self.state * 0x5DEECE66D + 0xB) & ((1 << 48) - 1)
+        v = self.state >> (48 - bits)
+        return v - (1 << 32) if v >= (1 << 31) else v  # the (int) cast
+
+    def next_int(self, bound: int) -> int:
+        r = self._next(31)
+        m = bound - 1
+        if bound & m == 0:
+            return (bound * r) >> 31
+        u = r
+        while True:
+            r = u % bound
+            if u - r + m < (1 << 31):
+                return r
+            u = self._next(31)
+
+    def next_double(self) -> float:
+        return ((self._next(26) << 27) + self._next(27)) * (1.0 / (1 << 53))
+
+
+# ------------------------------------------------------------------------------------------------
 # env.scala:32-255
 # ------------------------------------------------------------------------------------------------
 class EpidemicEnv:

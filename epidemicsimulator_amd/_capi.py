@@ -53,6 +53,12 @@ class CHyper(C.Structure):
                 ("batch_size", C.c_int32), ("learn_every", C.c_int32)]
 
 
+class LearnHyper(C.Structure):
+    _fields_ = [("gamma", C.c_double), ("lr", C.c_double), ("clip_q", C.c_double), ("grad_clip", C.c_double),
+                ("ema_alpha", C.c_double), ("hidden", C.c_int32), ("replay_capacity", C.c_int32),
+                ("target_update_every", C.c_int32), ("max_need", C.c_int32)]
+
+
 _PD = C.POINTER(C.c_double)
 _PI = C.POINTER(C.c_int32)
 _PU8 = C.POINTER(C.c_uint8)
@@ -81,6 +87,9 @@ EXPORTED_SYMBOLS = [
     "epi_grid_argmin", "epi_calibrate_grid", "epi_grid_set_timing", "epi_grid_kernel_time", "epi_world_create", "epi_world_step", "epi_world_step_greedy",
     "epi_world_set_mlp", "epi_world_get_states", "epi_world_set_states", "epi_world_reset", "epi_world_last_flows",
     "epi_world_set_timing", "epi_world_kernel_time", "epi_world_result_buffers", "epi_world_destroy",
+    "epi_agents_create", "epi_agents_destroy", "epi_agents_observe", "epi_agents_replay_size", "epi_agents_sample",
+    "epi_agents_learn", "epi_agents_q_values", "epi_agents_get_weights", "epi_agents_set_weights",
+    "epi_agents_set_timing", "epi_agents_kernel_time",
 ]
 
 _lib = None
@@ -111,6 +120,18 @@ def lib():
         L.epi_gravity_matrix.argtypes = [C.c_int32, _PI, _PD, _PD, _PD, C.c_double, C.c_double, C.c_double, C.c_double,
                                          C.c_double, _PD, C.c_int32]
         L.epi_grid_destroy.argtypes = [C.c_void_p]
+        L.epi_agents_create.restype = C.c_void_p
+        L.epi_agents_create.argtypes = [C.c_int32, C.POINTER(LearnHyper), C.c_int32]
+        L.epi_agents_destroy.argtypes = [C.c_void_p]
+        L.epi_agents_observe.argtypes = [C.c_void_p, _PI, C.c_int32, C.POINTER(CState), _PI, _PD, C.POINTER(CState), _PU8]
+        L.epi_agents_replay_size.argtypes = [C.c_void_p, _PI]
+        L.epi_agents_sample.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _PI, _PI]
+        L.epi_agents_learn.argtypes = [C.c_void_p, _PI, C.c_int32, _PI, _PI, C.POINTER(C.c_int64), _PD, _PD]
+        L.epi_agents_q_values.argtypes = [C.c_void_p, _PI, C.c_int32, C.POINTER(CState), C.c_int32, _PD, _PI]
+        L.epi_agents_get_weights.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [_PD] * 6
+        L.epi_agents_set_weights.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [_PD] * 6
+        L.epi_agents_set_timing.argtypes = [C.c_void_p, C.c_int32]
+        L.epi_agents_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         for name in ("epi_world_destroy", "epi_world_reset"):
             getattr(L, name).argtypes = [C.c_void_p]
         _lib = L

@@ -1,0 +1,667 @@
+// DDQN learners on the device: DDQNAgent.observe / ddqnTarget / learn (DDQNAgent.scala:34-65),
+// MLP.predict / trainBatch (MLP.scala:15-99) and ReplayBuffer (ReplayBuffer.scala:10-22) for a set of
+// independent agents (one per country in WorldToy.scala:46-65).
+//
+// Arithmetic contract: every sum the reference forms left to right is formed left to right here, one
+// rounding per operation (the file is compiled with -ffp-contract=off), so weights, Q-values and losses
+// are the same doubles.  That rules the matrix cores out (their accumulation order and fusing differ);
+// the contractions run on the vector ALUs, one output element per thread, sequential along the reduction
+// axis, weights read coalesced from L2.
+//
+// Division of labour: the replay ring and the shuffle of ReplayBuffer.sample (a sequential java.util.Random
+// walk over the whole buffer) live on the host; the sampled rows are staged in page-locked mapped memory
+// and everything from the three forward passes to the SGD step runs on the device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../../include/epi.h"
+#include "epi_host.hpp"
+#include "java_compat.hpp"
+
+#define EPI_API extern "C" __attribute__((visibility("default")))
+
+namespace epi {
+namespace {
+
+constexpr int kIn = 7;        // State.features (env.scala:28-30)
+constexpr int kOut = 8;       // Action.values.length
+constexpr int kXStride = 8;   // features padded to 8 doubles per row
+constexpr int kRows = 4;      // sample rows one workgroup carries through a layer (weights read once for all)
+constexpr int kMaxHidden = 256;
+
+// One network in device memory, every matrix with row stride Hp (hidden rounded up to 64):
+//   W1t[7][Hp]  b1[Hp]  W2[Hp][Hp] (row = output)  W2t[Hp][Hp] (row = input)  b2[Hp]  W3[8][Hp]  b3[8]
+struct NetLayout {
+    int H, Hp;
+    __host__ __device__ size_t w1t() const { return 0; }
+    __host__ __device__ size_t b1() const { return (size_t)kIn * Hp; }
+    __host__ __device__ size_t w2() const { return b1() + Hp; }
+    __host__ __device__ size_t w2t() const { return w2() + (size_t)Hp * Hp; }
+    __host__ __device__ size_t b2() const { return w2t() + (size_t)Hp * Hp; }
+    __host__ __device__ size_t w3() const { return b2() + Hp; }
+    __host__ __device__ size_t b3() const { return w3() + (size_t)kOut * Hp; }
+    __host__ __device__ size_t size() const { return b3() + kOut; }
+};
+
+struct AgentHyperDev {
+    double gamma, lr, clip_q, grad_clip;
+};
+
+// Arguments shared by the kernels of one call.  A "slot" is one agent taking part in the call.
+struct AgentsArgs {
+    NetLayout nl;
+    int Bp;                     // row capacity per slot and class (multiple of kRows)
+    int n_classes;              // learn: 3 (s/online, s2/online, s2/target); q-values: 1
+    int net_of_class[3];        // 0 = online, 1 = target
+    int x_of_class[3];          // which staged feature block the class reads (0 = s, 1 = s2)
+    double* nets;               // [n_agents][2] networks
+    const AgentHyperDev* hyper; // [n_agents]
+    const int32_t* slot_agent;  // [slots]
+    const int32_t* slot_rows;   // [slots] rows in use (need)
+    const double* X;            // [slots][2][Bp][kXStride]
+    const int32_t* act;         // [slots][Bp]
+    const double* rew;          // [slots][Bp]
+    const int32_t* done;        // [slots][Bp]
+    double* H1;                 // [slots][Bp][Hp]      class 0
+    double* H2;                 // [slots][Bp][Hp]      class 0
+    double* Q;                  // [slots][3][Bp][kOut] clamped outputs
+    double* DZ2;                // [slots][Bp][Hp]
+    double* DZ1;                // [slots][Bp][Hp]
+    double* ERR;                // [slots][Bp]  yC(a) - target(a)
+    double* loss;               // [slots]
+};
+
+__device__ inline double* net_ptr(const AgentsArgs& a, int agent, int which) {
+    return a.nets + ((size_t)agent * 2 + which) * a.nl.size();
+}
+__device__ inline double clip_sym(double v, double c) { return isfinite(c) ? fmax(-c, fmin(c, v)) : v; }
+
+// MLP.predict (MLP.scala:15-22) for kRows rows of one class of one slot.  Block = Hp threads, thread i owns
+// hidden unit i.  matVec sums left to right starting from the first product.
+__global__ void __launch_bounds__(kMaxHidden) agents_forward_kernel(AgentsArgs a) {
+    __shared__ double sh_x[kRows][kXStride];
+    __shared__ __align__(16) double sh_h[kMaxHidden][kRows];  // [unit][row]: one read brings all rows of a unit
+    const int slot = blockIdx.y, B = a.slot_rows[slot];
+    const int groups = a.Bp / kRows;
+    const int cls = blockIdx.x / groups, k0 = (blockIdx.x % groups) * kRows;
+    if (k0 >= B) return;
+    const int H = a.nl.H, Hp = a.nl.Hp, i = threadIdx.x;
+    const int agent = a.slot_agent[slot];
+    const double* net = net_ptr(a, agent, a.net_of_class[cls]);
+    const double clip_q = a.hyper[agent].clip_q;
+    const double* X = a.X + (((size_t)slot * 2 + a.x_of_class[cls]) * a.Bp + k0) * kXStride;
+    if (i < kRows * kXStride) sh_x[i / kXStride][i % kXStride] = (k0 + i / kXStride < B) ? X[i] : 0.0;
+    __syncthreads();
+    double h[kRows];
+    if (i < H) {
+        const double* W1t = net + a.nl.w1t();
+        double acc[kRows];
+        const double w0 = W1t[i];
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) acc[r] = w0 * sh_x[r][0];
+#pragma unroll
+        for (int j = 1; j < kIn; ++j) {
+            const double w = W1t[(size_t)j * Hp + i];
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) acc[r] = acc[r] + w * sh_x[r][j];
+        }
+        const double b = net[a.nl.b1() + i];
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            const double z = acc[r] + b;
+            h[r] = z > 0 ? z : 0.0;
+            sh_h[i][r] = h[r];
+            if (cls == 0 && k0 + r < B) a.H1[((size_t)slot * a.Bp + k0 + r) * Hp + i] = h[r];
+        }
+    }
+    __syncthreads();
+    if (i < H) {
+        const double* W2t = net + a.nl.w2t();
+        double acc[kRows];
+        const double w0 = W2t[i];
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) acc[r] = w0 * sh_h[0][r];
+        for (int j = 1; j < H; ++j) {
+            const double w = W2t[(size_t)j * Hp + i];
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) acc[r] = acc[r] + w * sh_h[j][r];
+        }
+        const double b = net[a.nl.b2() + i];
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            const double z = acc[r] + b;
+            h[r] = z > 0 ? z : 0.0;
+            if (cls == 0 && k0 + r < B) a.H2[((size_t)slot * a.Bp + k0 + r) * Hp + i] = h[r];
+        }
+    }
+    __syncthreads();  // every thread has finished reading the first hidden layer
+    if (i < H) {
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) sh_h[i][r] = h[r];
+    }
+    __syncthreads();
+    if (i < kOut * kRows) {
+        const int o = i % kOut, r = i / kOut;
+        if (k0 + r < B) {
+            const double* W3 = net + a.nl.w3() + (size_t)o * Hp;
+            double acc = W3[0] * sh_h[0][r];
+            for (int j = 1; j < H; ++j) acc = acc + W3[j] * sh_h[j][r];
+            const double y = acc + net[a.nl.b3() + o];
+            a.Q[(((size_t)slot * 3 + cls) * a.Bp + k0 + r) * kOut + o] = clip_sym(y, clip_q);
+        }
+    }
+}
+
+// ddqnTarget (DDQNAgent.scala:37-47) and the backward pass of MLP.trainBatch (MLP.scala:44-58) for kRows
+// samples.  The target equals the prediction in every component but the action taken, so err is zero there
+// and dh2(j) = W3(a)(j) * err(a).  dz = dh * relu(z) -- the activation's value, as the reference has it.
+__global__ void __launch_bounds__(kMaxHidden) agents_backward_kernel(AgentsArgs a) {
+    __shared__ __align__(16) double sh_dz[kMaxHidden][kRows];
+    __shared__ double sh_err[kRows];
+    const int slot = blockIdx.y, B = a.slot_rows[slot];
+    const int k0 = blockIdx.x * kRows;
+    if (k0 >= B) return;
+    const int H = a.nl.H, Hp = a.nl.Hp, j = threadIdx.x;
+    const int agent = a.slot_agent[slot];
+    const double* net = net_ptr(a, agent, 0);
+    const AgentHyperDev hp = a.hyper[agent];
+    if (j < kRows) {
+        const int k = k0 + j;
+        double err = 0.0;
+        if (k < B) {
+            const size_t row = (size_t)slot * a.Bp + k;
+            const double* q = a.Q + (((size_t)slot * 3 + 0) * a.Bp + k) * kOut;
+            const int act = a.act[row];
+            double tgt;
+            if (a.done[row]) {
+                tgt = fmax(-hp.clip_q, fmin(hp.clip_q, a.rew[row]));
+            } else {
+                const double* qn = a.Q + (((size_t)slot * 3 + 1) * a.Bp + k) * kOut;
+                const double* qt = a.Q + (((size_t)slot * 3 + 2) * a.Bp + k) * kOut;
+                int best = 0;  // zipWithIndex.maxBy(_._1): the first maximum
+                for (int o = 1; o < kOut; ++o)
+                    if (qn[o] > qn[best]) best = o;
+                tgt = fmax(-hp.clip_q, fmin(hp.clip_q, a.rew[row] + hp.gamma * qt[best]));
+            }
+            err = q[act] - tgt;
+            a.ERR[row] = err;
+        }
+        sh_err[j] = err;
+    }
+    __syncthreads();
+    if (j < H) {
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            double dz = 0.0;
+            if (k0 + r < B) {
+                const size_t row = (size_t)slot * a.Bp + k0 + r;
+                const double dh = net[a.nl.w3() + (size_t)a.act[row] * Hp + j] * sh_err[r];
+                dz = dh * a.H2[row * Hp + j];
+                a.DZ2[row * Hp + j] = dz;
+            }
+            sh_dz[j][r] = dz;
+        }
+    }
+    __syncthreads();
+    if (j < H) {
+        const double* W2 = net + a.nl.w2();
+        double acc[kRows];
+        const double w0 = W2[j];
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) acc[r] = w0 * sh_dz[0][r];
+        for (int i = 1; i < H; ++i) {
+            const double w = W2[(size_t)i * Hp + j];
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) acc[r] = acc[r] + w * sh_dz[i][r];
+        }
+#pragma unroll
+        for (int r = 0; r < kRows; ++r)
+            if (k0 + r < B) {
+                const size_t row = (size_t)slot * a.Bp + k0 + r;
+                a.DZ1[row * Hp + j] = acc[r] * a.H1[row * Hp + j];
+            }
+    }
+}
+
+// gW2(i)(j) = sum over samples, in sample order, of dz2(i) * h1(j) (MLP.scala:53,66), then mean, clip and
+// the SGD step (:78-93).  Block = Hp threads (j), kRows output rows i per block.  Both layouts are rewritten.
+__global__ void __launch_bounds__(kMaxHidden) agents_grad_w2_kernel(AgentsArgs a) {
+    const int slot = blockIdx.y, B = a.slot_rows[slot];
+    const int H = a.nl.H, Hp = a.nl.Hp, j = threadIdx.x, i0 = blockIdx.x * kRows;
+    if (j >= H || i0 >= H) return;
+    const int agent = a.slot_agent[slot];
+    double* net = net_ptr(a, agent, 0);
+    const AgentHyperDev hp = a.hyper[agent];
+    const double* H1 = a.H1 + (size_t)slot * a.Bp * Hp;
+    const double* DZ2 = a.DZ2 + (size_t)slot * a.Bp * Hp;
+    double acc[kRows];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) acc[r] = 0.0;
+    for (int k = 0; k < B; ++k) {
+        const double h = H1[(size_t)k * Hp + j];
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) acc[r] += DZ2[(size_t)k * Hp + i0 + r] * h;  // rows past H hold zeros
+    }
+    const double scale = 1.0 / (double)(B > 1 ? B : 1);
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        const int i = i0 + r;
+        if (i < H) {
+            const double g = clip_sym(acc[r] * scale, hp.grad_clip);
+            const double w = net[a.nl.w2() + (size_t)i * Hp + j] - hp.lr * g;
+            net[a.nl.w2() + (size_t)i * Hp + j] = w;
+            net[a.nl.w2t() + (size_t)j * Hp + i] = w;
+        }
+    }
+}
+
+// The remaining gradients, one thread per parameter, summed in sample order (MLP.scala:49-72), then mean,
+// clip, SGD (:78-96); the last thread forms the batch loss (:46,98).
+__global__ void __launch_bounds__(256) agents_grad_small_kernel(AgentsArgs a) {
+    const int slot = blockIdx.y, B = a.slot_rows[slot];
+    const int H = a.nl.H, Hp = a.nl.Hp;
+    const int agent = a.slot_agent[slot];
+    double* net = net_ptr(a, agent, 0);
+    const AgentHyperDev hp = a.hyper[agent];
+    const size_t base = (size_t)slot * a.Bp;
+    const double* X0 = a.X + ((size_t)slot * 2 + 0) * a.Bp * kXStride;
+    const double scale = 1.0 / (double)(B > 1 ? B : 1);
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc = 0.0;
+    size_t dst;
+    if (e < H * kIn) {  // gW1(i)(j) += dz1(i) * x(j)
+        const int i = e % H, j = e / H;
+        for (int k = 0; k < B; ++k) acc += a.DZ1[(base + k) * Hp + i] * X0[(size_t)k * kXStride + j];
+        dst = a.nl.w1t() + (size_t)j * Hp + i;
+    } else if ((e -= H * kIn) < H) {  // gb1
+        for (int k = 0; k < B; ++k) acc += a.DZ1[(base + k) * Hp + e];
+        dst = a.nl.b1() + e;
+    } else if ((e -= H) < H) {  // gb2
+        for (int k = 0; k < B; ++k) acc += a.DZ2[(base + k) * Hp + e];
+        dst = a.nl.b2() + e;
+    } else if ((e -= H) < kOut * H) {  // gW3(o)(j) += err(o) * h2(j): err is zero except at the action taken
+        const int j = e % H, o = e / H;
+        for (int k = 0; k < B; ++k)
+            if (a.act[base + k] == o) acc += a.ERR[base + k] * a.H2[(base + k) * Hp + j];
+        dst = a.nl.w3() + (size_t)o * Hp + j;
+    } else if ((e -= kOut * H) < kOut) {  // gb3
+        for (int k = 0; k < B; ++k)
+            if (a.act[base + k] == e) acc += a.ERR[base + k];
+        dst = a.nl.b3() + e;
+    } else if (e == kOut) {  // lossSum / n
+        for (int k = 0; k < B; ++k) {
+            const double er = a.ERR[base + k];
+            acc += 0.5 * er * er;
+        }
+        a.loss[slot] = acc / (double)(B > 1 ? B : 1);
+        return;
+    } else {
+        return;
+    }
+    net[dst] -= hp.lr * clip_sym(acc * scale, hp.grad_clip);
+}
+
+struct Transition {
+    double fs[kIn], fs2[kIn], r;
+    int32_t a, done;
+};
+
+// State.features (env.scala:26-30)
+void features(const epi_state& s, double* f) {
+    const double n = s.s + s.i + s.r + s.d;
+    const double N = std::fmax(1.0, n);
+    f[0] = s.s / N; f[1] = s.i / N; f[2] = s.r / N; f[3] = s.d / N; f[4] = s.v / N;
+    f[5] = s.i / std::fmax(1.0, s.hosp_cap);
+    f[6] = (double)s.t / (double)std::max(1, s.t_max);
+}
+
+struct Replay {  // ReplayBuffer.scala:10-22
+    std::vector<Transition> buf;
+    int capacity = 0, idx = 0;
+    JavaRandom rnd{123};
+    std::vector<int32_t> perm;
+    void push(const Transition& t) {
+        if ((int)buf.size() < capacity) buf.push_back(t);
+        else { buf[idx] = t; idx = (idx + 1) % capacity; }
+    }
+    // positions of rnd.shuffle(buf).take(n): scala.util.Random.shuffle copies the buffer and, for m from its length
+    // down to 2, swaps element m-1 with element nextInt(m)
+    const int32_t* sample() {
+        const int len = (int)buf.size();
+        perm.resize((size_t)len);
+        for (int i = 0; i < len; ++i) perm[i] = i;
+        for (int m = len; m >= 2; --m) std::swap(perm[m - 1], perm[rnd.nextInt(m)]);
+        return perm.data();
+    }
+};
+
+}  // namespace
+}  // namespace epi
+
+using namespace epi;
+
+struct epi_agents {
+    int device = 0, n = 0, Bp = 0;
+    NetLayout nl{};
+    std::vector<epi_learn_hyper> hp;
+    std::vector<Replay> replay;
+    std::vector<double> ema;
+    DevBuf nets, hyper, H1, H2, Q, DZ2, DZ1, ERR;
+    PinBuf slot_agent, slot_rows, X, act, rew, done, loss;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = false;
+    double kernel_ms = 0.0;
+    int64_t learn_calls = 0, samples = 0;
+    ~epi_agents() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    AgentsArgs args() const {
+        AgentsArgs a{};
+        a.nl = nl; a.Bp = Bp;
+        a.nets = nets.as<double>(); a.hyper = hyper.as<AgentHyperDev>();
+        a.slot_agent = slot_agent.on_device<int32_t>(); a.slot_rows = slot_rows.on_device<int32_t>();
+        a.X = X.on_device<double>(); a.act = act.on_device<int32_t>(); a.rew = rew.on_device<double>();
+        a.done = done.on_device<int32_t>();
+        a.H1 = H1.as<double>(); a.H2 = H2.as<double>(); a.Q = Q.as<double>(); a.DZ2 = DZ2.as<double>();
+        a.DZ1 = DZ1.as<double>(); a.ERR = ERR.as<double>(); a.loss = loss.on_device<double>();
+        return a;
+    }
+};
+
+namespace {
+
+// Host image of one network in the device layout.
+void pack_net(const NetLayout& nl, const double* W1, const double* b1, const double* W2, const double* b2,
+              const double* W3, const double* b3, double* out) {
+    std::fill(out, out + nl.size(), 0.0);
+    const int H = nl.H, Hp = nl.Hp;
+    for (int i = 0; i < H; ++i) {
+        for (int j = 0; j < kIn; ++j) out[nl.w1t() + (size_t)j * Hp + i] = W1[(size_t)i * kIn + j];
+        out[nl.b1() + i] = b1 ? b1[i] : 0.0;
+        for (int j = 0; j < H; ++j) {
+            out[nl.w2() + (size_t)i * Hp + j] = W2[(size_t)i * H + j];
+            out[nl.w2t() + (size_t)j * Hp + i] = W2[(size_t)i * H + j];
+        }
+        out[nl.b2() + i] = b2 ? b2[i] : 0.0;
+    }
+    for (int o = 0; o < kOut; ++o) {
+        for (int j = 0; j < H; ++j) out[nl.w3() + (size_t)o * Hp + j] = W3[(size_t)o * H + j];
+        out[nl.b3() + o] = b3 ? b3[o] : 0.0;
+    }
+}
+
+int32_t check_ids(const epi_agents* g, const int32_t* ids, int32_t count) {
+    if (count < 0 || count > g->n) return fail(EPI_ERR_BAD_ARGUMENT, "count %d outside [0,%d]", count, g->n);
+    if (!ids) return EPI_OK;
+    std::vector<char> seen((size_t)g->n, 0);
+    for (int k = 0; k < count; ++k) {
+        if (ids[k] < 0 || ids[k] >= g->n) return fail(EPI_ERR_BAD_ARGUMENT, "agent id %d outside [0,%d)", ids[k], g->n);
+        if (seen[ids[k]]) return fail(EPI_ERR_BAD_ARGUMENT, "agent id %d listed twice", ids[k]);
+        seen[ids[k]] = 1;
+    }
+    return EPI_OK;
+}
+
+}  // namespace
+
+EPI_API epi_agents* epi_agents_create(int32_t n_agents, const epi_learn_hyper* hp, int32_t device) {
+    if (n_agents <= 0 || !hp) { fail(EPI_ERR_BAD_ARGUMENT, "agents: n_agents = %d, hp = %p", n_agents, (const void*)hp); return nullptr; }
+    const int H = hp[0].hidden;
+    int max_need = 0;
+    for (int k = 0; k < n_agents; ++k) {
+        if (hp[k].hidden != H) { fail(EPI_ERR_UNSUPPORTED, "agents: one handle holds agents of one hidden width (%d vs %d)", hp[k].hidden, H); return nullptr; }
+        if (hp[k].replay_capacity <= 0 || hp[k].target_update_every <= 0 || hp[k].max_need <= 0) {
+            fail(EPI_ERR_BAD_ARGUMENT, "agents: agent %d: replay_capacity, target_update_every and max_need must be positive", k);
+            return nullptr;
+        }
+        max_need = std::max(max_need, hp[k].max_need);
+    }
+    if (H < 1 || H > kMaxHidden) { fail(EPI_ERR_UNSUPPORTED, "agents: hidden = %d outside [1,%d]", H, kMaxHidden); return nullptr; }
+    if (use_device(device) != EPI_OK) return nullptr;
+    std::unique_ptr<epi_agents> g(new epi_agents);
+    g->device = device; g->n = n_agents;
+    g->nl.H = H; g->nl.Hp = (H + 63) / 64 * 64;
+    g->Bp = (max_need + kRows - 1) / kRows * kRows;
+    g->hp.assign(hp, hp + n_agents);
+    g->replay.resize((size_t)n_agents);
+    g->ema.assign((size_t)n_agents, 0.0);
+    for (int k = 0; k < n_agents; ++k) g->replay[k].capacity = hp[k].replay_capacity;
+    auto ok = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess) { fail(EPI_ERR_DEVICE, "agents: %s: %s", what, hipGetErrorString(e)); return false; }
+        return true;
+    };
+    // DDQNAgent.scala:8-9: both networks start from the same Random(7) stream (MLP.scala:5-9)
+    std::vector<double> W1, W2, W3, one(g->nl.size()), all((size_t)n_agents * 2 * g->nl.size());
+    mlp_init(kIn, H, kOut, W1, W2, W3);
+    pack_net(g->nl, W1.data(), nullptr, W2.data(), nullptr, W3.data(), nullptr, one.data());
+    for (int k = 0; k < n_agents * 2; ++k) std::copy(one.begin(), one.end(), all.begin() + (size_t)k * g->nl.size());
+    std::vector<AgentHyperDev> hd((size_t)n_agents);
+    for (int k = 0; k < n_agents; ++k) hd[k] = {hp[k].gamma, hp[k].lr, hp[k].clip_q, hp[k].grad_clip};
+    const size_t rows = (size_t)n_agents * g->Bp, Hp = (size_t)g->nl.Hp;
+    if (!ok(g->nets.upload(all), "networks") || !ok(g->hyper.upload(hd), "hyper") ||
+        !ok(g->H1.ensure(rows * Hp * 8), "H1") || !ok(g->H2.ensure(rows * Hp * 8), "H2") ||
+        !ok(g->Q.ensure(rows * 3 * kOut * 8), "Q") || !ok(g->DZ2.ensure(rows * Hp * 8), "DZ2") ||
+        !ok(g->DZ1.ensure(rows * Hp * 8), "DZ1") || !ok(g->ERR.ensure(rows * 8), "ERR") ||
+        !ok(g->slot_agent.ensure((size_t)n_agents * 4), "slots") || !ok(g->slot_rows.ensure((size_t)n_agents * 4), "slots") ||
+        !ok(g->X.ensure(rows * 2 * kXStride * 8), "X") || !ok(g->act.ensure(rows * 4), "act") ||
+        !ok(g->rew.ensure(rows * 8), "rew") || !ok(g->done.ensure(rows * 4), "done") ||
+        !ok(g->loss.ensure((size_t)n_agents * 8), "loss") ||
+        !ok(hipMemset(g->DZ2.p, 0, rows * Hp * 8), "clear") ||  // columns past H are read by the gradient kernel
+        !ok(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking), "stream") ||
+        !ok(hipEventCreate(&g->ev0), "event") || !ok(hipEventCreate(&g->ev1), "event"))
+        return nullptr;
+    return g.release();
+}
+
+EPI_API int32_t epi_agents_destroy(epi_agents* g) {
+    if (!g) return EPI_OK;
+    (void)hipSetDevice(g->device);
+    (void)hipStreamSynchronize(g->stream);
+    delete g;
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_agents_observe(epi_agents* g, const int32_t* ids, int32_t count, const epi_state* s, const int32_t* a,
+                                   const double* r, const epi_state* s2, const uint8_t* done) {
+    if (!g || !s || !a || !r || !s2 || !done) return fail(EPI_ERR_BAD_ARGUMENT, "agents_observe: null argument");
+    if (int32_t rc = check_ids(g, ids, count)) return rc;
+    for (int k = 0; k < count; ++k) {
+        if (a[k] < 0 || a[k] >= kOut) return fail(EPI_ERR_BAD_ARGUMENT, "agents_observe: action %d outside [0,%d)", a[k], kOut);
+        Transition t;
+        features(s[k], t.fs); features(s2[k], t.fs2);
+        t.a = a[k]; t.r = r[k]; t.done = done[k] ? 1 : 0;
+        g->replay[ids ? ids[k] : k].push(t);
+    }
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_agents_replay_size(epi_agents* g, int32_t* sizes) {
+    if (!g || !sizes) return fail(EPI_ERR_BAD_ARGUMENT, "agents_replay_size: null argument");
+    for (int k = 0; k < g->n; ++k) sizes[k] = (int32_t)g->replay[k].buf.size();
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_agents_sample(epi_agents* g, int32_t agent, int32_t n, int32_t* out, int32_t* taken) {
+    if (!g || !out || !taken || agent < 0 || agent >= g->n || n < 0) return fail(EPI_ERR_BAD_ARGUMENT, "agents_sample: bad argument");
+    Replay& rp = g->replay[agent];
+    const int32_t* p = rp.sample();
+    *taken = std::min<int32_t>(n, (int32_t)rp.buf.size());
+    std::copy(p, p + *taken, out);
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_agents_learn(epi_agents* g, const int32_t* ids, int32_t count, const int32_t* batch,
+                                 const int32_t* grad_accum, const int64_t* steps, double* loss, double* ema_loss) {
+    if (!g || !batch || !grad_accum || !steps || !loss) return fail(EPI_ERR_BAD_ARGUMENT, "agents_learn: null argument");
+    if (int32_t rc = check_ids(g, ids, count)) return rc;
+    if (int32_t rc = use_device(g->device)) return rc;
+    // DDQNAgent.scala:52-54: agents whose buffer is short return 0.0 and draw nothing
+    std::vector<int> slot_of((size_t)count, -1);
+    int slots = 0;
+    int32_t* sa = g->slot_agent.as<int32_t>();
+    int32_t* sr = g->slot_rows.as<int32_t>();
+    for (int k = 0; k < count; ++k) {
+        const int id = ids ? ids[k] : k;
+        if (batch[k] <= 0 || grad_accum[k] <= 0) return fail(EPI_ERR_BAD_ARGUMENT, "agents_learn: batch and grad_accum must be positive");
+        const int64_t need64 = std::max<int64_t>((int64_t)batch[k] * grad_accum[k], batch[k]);
+        loss[k] = 0.0;
+        if ((int64_t)g->replay[id].buf.size() < need64) continue;
+        if (need64 > g->hp[id].max_need)
+            return fail(EPI_ERR_BAD_ARGUMENT, "agents_learn: agent %d needs %lld samples, the handle was created for %d", id, (long long)need64, g->hp[id].max_need);
+        slot_of[k] = slots;
+        sa[slots] = id; sr[slots] = (int32_t)need64;
+        ++slots;
+    }
+    if (slots > 0) {
+        const int Bp = g->Bp;
+        for (int k = 0; k < count; ++k) {
+            if (slot_of[k] < 0) continue;
+            const int sl = slot_of[k], id = sa[sl], need = sr[sl];
+            Replay& rp = g->replay[id];
+            const int32_t* p = rp.sample();
+            double* X0 = g->X.as<double>() + ((size_t)sl * 2 + 0) * Bp * kXStride;
+            double* X1 = g->X.as<double>() + ((size_t)sl * 2 + 1) * Bp * kXStride;
+            for (int q = 0; q < need; ++q) {
+                const Transition& t = rp.buf[(size_t)p[q]];
+                std::memcpy(X0 + (size_t)q * kXStride, t.fs, sizeof t.fs); X0[(size_t)q * kXStride + 7] = 0.0;
+                std::memcpy(X1 + (size_t)q * kXStride, t.fs2, sizeof t.fs2); X1[(size_t)q * kXStride + 7] = 0.0;
+                g->act.as<int32_t>()[(size_t)sl * Bp + q] = t.a;
+                g->rew.as<double>()[(size_t)sl * Bp + q] = t.r;
+                g->done.as<int32_t>()[(size_t)sl * Bp + q] = t.done;
+            }
+        }
+        AgentsArgs a = g->args();
+        a.n_classes = 3;
+        a.net_of_class[0] = 0; a.net_of_class[1] = 0; a.net_of_class[2] = 1;
+        a.x_of_class[0] = 0; a.x_of_class[1] = 1; a.x_of_class[2] = 1;
+        const int Hp = g->nl.Hp, H = g->nl.H;
+        if (g->timing) HIP_TRY(hipEventRecord(g->ev0, g->stream));
+        hipLaunchKernelGGL(agents_forward_kernel, dim3(3 * Bp / kRows, slots), dim3(Hp), 0, g->stream, a);
+        hipLaunchKernelGGL(agents_backward_kernel, dim3(Bp / kRows, slots), dim3(Hp), 0, g->stream, a);
+        hipLaunchKernelGGL(agents_grad_w2_kernel, dim3((H + kRows - 1) / kRows, slots), dim3(Hp), 0, g->stream, a);
+        hipLaunchKernelGGL(agents_grad_small_kernel, dim3((17 * H + 9 + 255) / 256, slots), dim3(256), 0, g->stream, a);
+        HIP_TRY(hipGetLastError());
+        // DDQNAgent.scala:59-61: the target network follows the updated online network
+        for (int sl = 0; sl < slots; ++sl) {
+            const int id = sa[sl];
+            int kk = 0;
+            while (slot_of[kk] != sl) ++kk;
+            if (steps[kk] % g->hp[id].target_update_every == 0) {
+                double* on = g->nets.as<double>() + ((size_t)id * 2) * g->nl.size();
+                HIP_TRY(hipMemcpyAsync(on + g->nl.size(), on, g->nl.size() * 8, hipMemcpyDeviceToDevice, g->stream));
+            }
+        }
+        if (g->timing) HIP_TRY(hipEventRecord(g->ev1, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        if (g->timing) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, g->ev0, g->ev1));
+            g->kernel_ms += ms; g->learn_calls += 1;
+            for (int sl = 0; sl < slots; ++sl) g->samples += sr[sl];
+        }
+        for (int k = 0; k < count; ++k) {
+            if (slot_of[k] < 0) continue;
+            const int id = sa[slot_of[k]];
+            loss[k] = g->loss.as<double>()[slot_of[k]];
+            const double al = g->hp[id].ema_alpha;  // DDQNAgent.scala:63
+            g->ema[id] = (g->ema[id] == 0.0) ? loss[k] : al * loss[k] + (1 - al) * g->ema[id];
+        }
+    }
+    if (ema_loss)
+        for (int k = 0; k < count; ++k) ema_loss[k] = g->ema[ids ? ids[k] : k];
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_agents_q_values(epi_agents* g, const int32_t* ids, int32_t count, const epi_state* s, int32_t use_target,
+                                    double* q, int32_t* greedy) {
+    if (!g || !s || (!q && !greedy)) return fail(EPI_ERR_BAD_ARGUMENT, "agents_q_values: null argument");
+    if (int32_t rc = check_ids(g, ids, count)) return rc;
+    if (count == 0) return EPI_OK;
+    if (int32_t rc = use_device(g->device)) return rc;
+    const int Bp = g->Bp;
+    for (int k = 0; k < count; ++k) {
+        g->slot_agent.as<int32_t>()[k] = ids ? ids[k] : k;
+        g->slot_rows.as<int32_t>()[k] = 1;
+        double* X0 = g->X.as<double>() + ((size_t)k * 2 + 0) * Bp * kXStride;
+        features(s[k], X0); X0[7] = 0.0;
+    }
+    AgentsArgs a = g->args();
+    a.n_classes = 1;
+    a.net_of_class[0] = use_target ? 1 : 0; a.x_of_class[0] = 0;
+    // class 0 also writes the hidden activations of row 0 of each slot: scratch no later call relies on
+    hipLaunchKernelGGL(agents_forward_kernel, dim3(1, count), dim3(g->nl.Hp), 0, g->stream, a);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> out((size_t)count * kOut);
+    for (int k = 0; k < count; ++k)
+        HIP_TRY(hipMemcpyAsync(out.data() + (size_t)k * kOut, g->Q.as<double>() + ((size_t)k * 3) * Bp * kOut, kOut * 8,
+                               hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    for (int k = 0; k < count; ++k) {
+        const double* y = out.data() + (size_t)k * kOut;
+        if (q) std::copy(y, y + kOut, q + (size_t)k * kOut);
+        if (greedy) {
+            int best = 0;
+            for (int o = 1; o < kOut; ++o)
+                if (y[o] > y[best]) best = o;
+            greedy[k] = best;
+        }
+    }
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_agents_get_weights(epi_agents* g, int32_t agent, int32_t target, double* W1, double* b1, double* W2,
+                                       double* b2, double* W3, double* b3) {
+    if (!g || agent < 0 || agent >= g->n) return fail(EPI_ERR_BAD_ARGUMENT, "agents_get_weights: bad argument");
+    if (int32_t rc = use_device(g->device)) return rc;
+    const NetLayout& nl = g->nl;
+    std::vector<double> img(nl.size());
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    HIP_TRY(hipMemcpy(img.data(), g->nets.as<double>() + ((size_t)agent * 2 + (target ? 1 : 0)) * nl.size(), nl.size() * 8,
+                      hipMemcpyDeviceToHost));
+    const int H = nl.H, Hp = nl.Hp;
+    for (int i = 0; i < H; ++i) {
+        if (W1) for (int j = 0; j < kIn; ++j) W1[(size_t)i * kIn + j] = img[nl.w1t() + (size_t)j * Hp + i];
+        if (b1) b1[i] = img[nl.b1() + i];
+        if (W2) for (int j = 0; j < H; ++j) W2[(size_t)i * H + j] = img[nl.w2() + (size_t)i * Hp + j];
+        if (b2) b2[i] = img[nl.b2() + i];
+    }
+    for (int o = 0; o < kOut; ++o) {
+        if (W3) for (int j = 0; j < H; ++j) W3[(size_t)o * H + j] = img[nl.w3() + (size_t)o * Hp + j];
+        if (b3) b3[o] = img[nl.b3() + o];
+    }
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_agents_set_weights(epi_agents* g, int32_t agent, int32_t target, const double* W1, const double* b1,
+                                       const double* W2, const double* b2, const double* W3, const double* b3) {
+    if (!g || agent < 0 || agent >= g->n || !W1 || !W2 || !W3) return fail(EPI_ERR_BAD_ARGUMENT, "agents_set_weights: bad argument");
+    if (int32_t rc = use_device(g->device)) return rc;
+    std::vector<double> img(g->nl.size());
+    pack_net(g->nl, W1, b1, W2, b2, W3, b3, img.data());
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    HIP_TRY(hipMemcpy(g->nets.as<double>() + ((size_t)agent * 2 + (target ? 1 : 0)) * g->nl.size(), img.data(),
+                      g->nl.size() * 8, hipMemcpyHostToDevice));
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_agents_set_timing(epi_agents* g, int32_t on) {
+    if (!g) return fail(EPI_ERR_BAD_ARGUMENT, "agents_set_timing: null handle");
+    g->timing = on != 0; g->kernel_ms = 0.0; g->learn_calls = 0; g->samples = 0;
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_agents_kernel_time(epi_agents* g, double* total_ms, int64_t* learn_calls, int64_t* samples) {
+    if (!g) return fail(EPI_ERR_BAD_ARGUMENT, "agents_kernel_time: null handle");
+    if (total_ms) *total_ms = g->kernel_ms;
+    if (learn_calls) *learn_calls = g->learn_calls;
+    if (samples) *samples = g->samples;
+    return EPI_OK;
+}

@@ -117,10 +117,12 @@ double strict_log(double x) {
 }
 
 int AgentStream::act(const Hyper& hp) {
-    steps += 1;
+    // act(s) = actWithEpsilon(s, epsilon, countStep = true): the argument is evaluated before the call, so
+    // epsilon is read with the step count as it was, and the count goes up inside (DDQNAgent.scala:26-27,32)
     const int32_t den = hp.epsilon_decay_steps > 1 ? hp.epsilon_decay_steps : 1;
     const double frac = std::fmin(1.0, static_cast<double>(steps) / static_cast<double>(den));
     const double eps = hp.epsilon_start + (hp.epsilon_end - hp.epsilon_start) * frac;
+    steps += 1;
     if (rnd.nextDouble() < eps) return rnd.nextInt(8);
     return kGreedyAction;
 }

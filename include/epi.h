@@ -216,6 +216,54 @@ int32_t epi_world_set_timing(epi_world *w, int32_t on);
 int32_t epi_world_kernel_time(epi_world *w, double *total_ms, int64_t *launches, int64_t *country_steps);
 int32_t epi_world_destroy(epi_world *w);
 
+/* ---- DDQNAgent learning (DDQNAgent.scala:6-70) with MLP.trainBatch (MLP.scala:29-99) and
+ *      ReplayBuffer (ReplayBuffer.scala:10-22): one agent per country (WorldToy.scala:46-65) ------ */
+/* HyperParams fields the learn step reads (config.scala:3-21), one record per agent. */
+typedef struct epi_learn_hyper {
+    double gamma, lr, clip_q, grad_clip, ema_alpha;
+    int32_t hidden;              /* one width per handle */
+    int32_t replay_capacity;
+    int32_t target_update_every;
+    int32_t max_need;            /* largest batch * gradAccumSteps epi_agents_learn will be asked for */
+} epi_learn_hyper;
+
+typedef struct epi_agents epi_agents;
+
+/* n_agents fresh agents (two networks each from MLP.scala:5-9, empty replay buffers whose shuffle stream is
+ * Random(123)) on `device`.  Returns NULL on failure. */
+epi_agents *epi_agents_create(int32_t n_agents, const epi_learn_hyper *hp, int32_t device);
+int32_t epi_agents_destroy(epi_agents *g);
+/* DDQNAgent.observe (:34): one Transition(s, a, r, s2, done) for each of `count` agents; ids = NULL means
+ * agents 0..count-1.  The buffers keep State.features of s and s2, the only parts learn() reads. */
+int32_t epi_agents_observe(epi_agents *g, const int32_t *ids, int32_t count, const epi_state *s, const int32_t *a,
+                           const double *r, const epi_state *s2, const uint8_t *done);
+/* DDQNAgent.replaySize (:69) of every agent: sizes[n_agents]. */
+int32_t epi_agents_replay_size(epi_agents *g, int32_t *sizes);
+/* ReplayBuffer.sample (ReplayBuffer.scala:21-22): buffer positions of rnd.shuffle(buf).take(n); advances the
+ * agent's shuffle stream exactly as one sample() call does. */
+int32_t epi_agents_sample(epi_agents *g, int32_t agent, int32_t n, int32_t *out, int32_t *taken);
+/* DDQNAgent.learn(batch, gradAccumSteps) (:51-65) for `count` agents in one set of launches.  steps[k] is the
+ * agent's act() counter (:12,27), which decides the target-network copy (:59-61).  loss[k] is learn's return
+ * value (0.0, and nothing drawn, while the buffer holds fewer than batch*gradAccumSteps transitions);
+ * ema_loss[k] (may be NULL) is emaLossNow (:68) afterwards. */
+int32_t epi_agents_learn(epi_agents *g, const int32_t *ids, int32_t count, const int32_t *batch,
+                         const int32_t *grad_accum, const int64_t *steps, double *loss, double *ema_loss);
+/* DDQNAgent.qValues / actGreedy (:22-23,70): q[count][8] (may be NULL) and the first argmax greedy[count]
+ * (may be NULL) of one state per agent; use_target != 0 evaluates the target network instead. */
+int32_t epi_agents_q_values(epi_agents *g, const int32_t *ids, int32_t count, const epi_state *s, int32_t use_target,
+                            double *q, int32_t *greedy);
+/* Weights in the reference's layout: W1[h][7], b1[h], W2[h][h], b2[h], W3[8][h], b3[8] (any get pointer may
+ * be NULL; NULL biases in set mean zero).  For checkpoints and for handing a trained network to
+ * epi_world_set_mlp. */
+int32_t epi_agents_get_weights(epi_agents *g, int32_t agent, int32_t target, double *W1, double *b1, double *W2,
+                               double *b2, double *W3, double *b3);
+int32_t epi_agents_set_weights(epi_agents *g, int32_t agent, int32_t target, const double *W1, const double *b1,
+                               const double *W2, const double *b2, const double *W3, const double *b3);
+/* Measurement hooks (no counterpart in the reference): device time of the learn launches, their number and
+ * the samples they trained on since timing was switched on. */
+int32_t epi_agents_set_timing(epi_agents *g, int32_t on);
+int32_t epi_agents_kernel_time(epi_agents *g, double *total_ms, int64_t *learn_calls, int64_t *samples);
+
 #ifdef __cplusplus
 }
 #endif

@@ -777,8 +777,10 @@ EXPORT void orc_world_step(void *h, int32_t t_max, int32_t greedy, double *rewar
             mlp_predict(&w->net, f7, w->hp.clip_q, q);
             a = argmax_first(q, 8);
         } else {
-            ag->steps += 1;                               /* countStep */
+            /* act(s) = actWithEpsilon(s, epsilon, countStep = true): epsilon is an argument, evaluated
+             * with the step count before the call increments it (DDQNAgent.scala:26-27,32) */
             double eps = agent_epsilon(ag, &w->hp);
+            ag->steps += 1;                               /* countStep */
             if (jr_next_double(&ag->rnd) < eps) a = jr_next_int_bound(&ag->rnd, 8);
             else {
                 orc_features(&w->cur[c], f7);
@@ -929,4 +931,197 @@ EXPORT int64_t orc_bench_points(int32_t n, const int32_t *pop, const double *W, 
     *checksum = cs;
     free(arr); free(pk); free(fin);
     return done;
+}
+
+/* ------------------------------------------------------------------------ */
+/* DDQN learner: ReplayBuffer (ReplayBuffer.scala:10-22), MLP.trainBatch      */
+/* (MLP.scala:29-99), DDQNAgent.observe/ddqnTarget/learn (DDQNAgent.scala:    */
+/* 34-65).  Parity unpinned with respect to a live JVM run: the reference's   */
+/* only test of this code (ReplayBufferSpec.scala) checks determinism and set */
+/* membership, both of which the tests repeat.  scala.util.Random.shuffle is  */
+/* the Scala 2.13 library routine (a third-party dependency absent from the   */
+/* reference tree): copy, then for n = length down to 2 swap(n-1, nextInt(n)).*/
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    double gamma, lr, clip_q, grad_clip, ema_alpha;
+    int32_t hidden, replay_capacity, target_update_every, max_need;
+} orc_learn_hyper;
+
+typedef struct {
+    double fs[7], fs2[7], r;
+    int32_t a, done;
+} transition;
+
+typedef struct {
+    orc_learn_hyper hp;
+    mlp online, target;
+    transition *buf;
+    int32_t size, idx;
+    jrand rnd; /* ReplayBuffer.scala:13 Random(123) */
+    int64_t steps;
+    double ema;
+} learner;
+
+/* xs.sum on a non-empty collection: reduce(_ + _), left to right */
+static double reduce_sum(const double *x, int n) {
+    double acc = x[0];
+    for (int k = 1; k < n; k++) acc = acc + x[k];
+    return acc;
+}
+static double clip_sym(double v, double c) { return isfinite(c) ? fmax(-c, fmin(c, v)) : v; } /* MLP.scala:24-27 */
+
+/* forward pass keeping the pre-activations (MLP.scala:39-42) */
+static void mlp_forward(const mlp *m, const double *x, double clamp, double *z1, double *h1, double *z2, double *h2,
+                        double *y, double *yc) {
+    matvec(m->W1, x, m->h, m->in, z1);
+    for (int k = 0; k < m->h; k++) { z1[k] = z1[k] + m->b1[k]; h1[k] = z1[k] > 0 ? z1[k] : 0.0; }
+    matvec(m->W2, h1, m->h, m->h, z2);
+    for (int k = 0; k < m->h; k++) { z2[k] = z2[k] + m->b2[k]; h2[k] = z2[k] > 0 ? z2[k] : 0.0; }
+    matvec(m->W3, h2, m->out, m->h, y);
+    for (int k = 0; k < m->out; k++) { y[k] = y[k] + m->b3[k]; yc[k] = clip_sym(y[k], clamp); }
+}
+
+/* MLP.trainBatch (MLP.scala:29-99): per-sample backprop accumulated in sample order, mean, clip, SGD. */
+static double mlp_train_batch(mlp *m, const double *xs, const double *tgts, int n, double grad_clip, double clamp,
+                              double lr) {
+    const int in = m->in, h = m->h, out = m->out;
+    double *gW1 = calloc((size_t)h * in, 8), *gb1 = calloc((size_t)h, 8), *gW2 = calloc((size_t)h * h, 8);
+    double *gb2 = calloc((size_t)h, 8), *gW3 = calloc((size_t)out * h, 8), *gb3 = calloc((size_t)out, 8);
+    double *z1 = malloc(8 * (size_t)h), *h1 = malloc(8 * (size_t)h), *z2 = malloc(8 * (size_t)h), *h2 = malloc(8 * (size_t)h);
+    double *dh2 = malloc(8 * (size_t)h), *dz2 = malloc(8 * (size_t)h), *dh1 = malloc(8 * (size_t)h), *dz1 = malloc(8 * (size_t)h);
+    double *tmp = malloc(8 * (size_t)(h > out ? h : out));
+    double y[64], yc[64], err[64], sq[64];
+    double loss_sum = 0.0;
+    for (int k = 0; k < n; k++) {
+        const double *x0 = xs + (size_t)k * in, *tgt = tgts + (size_t)k * out;
+        mlp_forward(m, x0, clamp, z1, h1, z2, h2, y, yc);
+        for (int i = 0; i < out; i++) { err[i] = yc[i] - tgt[i]; sq[i] = 0.5 * err[i] * err[i]; }
+        loss_sum += reduce_sum(sq, out);
+        /* backprop (:49-58); note dz = dh * relu(z), the value and not the derivative, as the reference has it */
+        for (int j = 0; j < h; j++) {
+            for (int i = 0; i < out; i++) tmp[i] = m->W3[(size_t)i * h + j] * err[i];
+            dh2[j] = reduce_sum(tmp, out);
+            dz2[j] = dh2[j] * (z2[j] > 0 ? z2[j] : 0.0);
+        }
+        for (int j = 0; j < h; j++) {
+            for (int i = 0; i < h; i++) tmp[i] = m->W2[(size_t)i * h + j] * dz2[i];
+            dh1[j] = reduce_sum(tmp, h);
+            dz1[j] = dh1[j] * (z1[j] > 0 ? z1[j] : 0.0);
+        }
+        /* accumulate (:61-72) */
+        for (int i = 0; i < out; i++) for (int j = 0; j < h; j++) gW3[(size_t)i * h + j] += err[i] * h2[j];
+        for (int i = 0; i < out; i++) gb3[i] += err[i];
+        for (int i = 0; i < h; i++) for (int j = 0; j < h; j++) gW2[(size_t)i * h + j] += dz2[i] * h1[j];
+        for (int i = 0; i < h; i++) gb2[i] += dz2[i];
+        for (int i = 0; i < h; i++) for (int j = 0; j < in; j++) gW1[(size_t)i * in + j] += dz1[i] * x0[j];
+        for (int i = 0; i < h; i++) gb1[i] += dz1[i];
+    }
+    const double scale = 1.0 / (double)(n > 1 ? n : 1); /* :78 */
+#define STEP(W, g, cnt) for (size_t q = 0; q < (size_t)(cnt); q++) { double gg = clip_sym((g)[q] * scale, grad_clip); (W)[q] -= lr * gg; }
+    STEP(m->W3, gW3, out * h) STEP(m->b3, gb3, out) STEP(m->W2, gW2, h * h) STEP(m->b2, gb2, h)
+    STEP(m->W1, gW1, h * in) STEP(m->b1, gb1, h)
+#undef STEP
+    free(gW1); free(gb1); free(gW2); free(gb2); free(gW3); free(gb3);
+    free(z1); free(h1); free(z2); free(h2); free(dh2); free(dz2); free(dh1); free(dz1); free(tmp);
+    return loss_sum / (double)(n > 1 ? n : 1);
+}
+
+static void mlp_copy(mlp *dst, const mlp *src) { /* MLP.copyFrom :101-109 */
+    memcpy(dst->W1, src->W1, 8 * (size_t)src->h * src->in); memcpy(dst->b1, src->b1, 8 * (size_t)src->h);
+    memcpy(dst->W2, src->W2, 8 * (size_t)src->h * src->h); memcpy(dst->b2, src->b2, 8 * (size_t)src->h);
+    memcpy(dst->W3, src->W3, 8 * (size_t)src->out * src->h); memcpy(dst->b3, src->b3, 8 * (size_t)src->out);
+}
+
+EXPORT void *orc_learner_create(const orc_learn_hyper *hp) {
+    learner *L = (learner *)calloc(1, sizeof(learner));
+    L->hp = *hp;
+    mlp_init(&L->online, 7, hp->hidden, 8); /* DDQNAgent.scala:8-9: two networks, same fixed init seed */
+    mlp_init(&L->target, 7, hp->hidden, 8);
+    L->buf = (transition *)calloc((size_t)(hp->replay_capacity > 0 ? hp->replay_capacity : 1), sizeof(transition));
+    jr_init(&L->rnd, 123);
+    return L;
+}
+EXPORT void orc_learner_destroy(void *h) {
+    learner *L = (learner *)h;
+    mlp_free(&L->online); mlp_free(&L->target); free(L->buf); free(L);
+}
+/* DDQNAgent.observe -> ReplayBuffer.push (ReplayBuffer.scala:15-17); only the features of s and s2 are ever read */
+EXPORT void orc_learner_observe(void *h, const orc_state *s, int32_t a, double r, const orc_state *s2, int32_t done) {
+    learner *L = (learner *)h;
+    transition t;
+    orc_features(s, t.fs); orc_features(s2, t.fs2);
+    t.a = a; t.r = r; t.done = done;
+    if (L->size < L->hp.replay_capacity) L->buf[L->size++] = t;
+    else { L->buf[L->idx] = t; L->idx = (L->idx + 1) % L->hp.replay_capacity; }
+}
+EXPORT int32_t orc_learner_replay_size(void *h) { return ((learner *)h)->size; }
+EXPORT void orc_learner_set_steps(void *h, int64_t steps) { ((learner *)h)->steps = steps; }
+EXPORT double orc_learner_ema_loss(void *h) { return ((learner *)h)->ema; }
+
+/* ReplayBuffer.sample (ReplayBuffer.scala:21-22): positions of the first n elements of rnd.shuffle(buf) */
+EXPORT int32_t orc_learner_sample(void *h, int32_t n, int32_t *out) {
+    learner *L = (learner *)h;
+    const int len = L->size;
+    int32_t *p = (int32_t *)malloc(sizeof(int32_t) * (size_t)(len > 0 ? len : 1));
+    for (int i = 0; i < len; i++) p[i] = i;
+    for (int m = len; m >= 2; m--) {
+        int k = jr_next_int_bound(&L->rnd, m);
+        int32_t t = p[m - 1]; p[m - 1] = p[k]; p[k] = t;
+    }
+    const int take = n < len ? n : len;
+    for (int i = 0; i < take; i++) out[i] = p[i];
+    free(p);
+    return take;
+}
+
+static double learner_clip_q(const learner *L, double x) { return fmax(-L->hp.clip_q, fmin(L->hp.clip_q, x)); } /* :49 */
+
+/* DDQNAgent.learn (DDQNAgent.scala:51-65) */
+EXPORT double orc_learner_learn(void *h, int32_t batch, int32_t grad_accum) {
+    learner *L = (learner *)h;
+    const int need = batch * grad_accum > batch ? batch * grad_accum : batch;
+    if (L->size < need) return 0.0;
+    int32_t *ix = (int32_t *)malloc(sizeof(int32_t) * (size_t)need);
+    orc_learner_sample(L, need, ix);
+    double *xs = (double *)malloc(8 * (size_t)need * 7), *tg = (double *)malloc(8 * (size_t)need * 8);
+    double qn[8], qt[8];
+    for (int k = 0; k < need; k++) {
+        const transition *e = &L->buf[ix[k]];
+        memcpy(xs + (size_t)k * 7, e->fs, 56);
+        double *q = tg + (size_t)k * 8; /* ddqnTarget :37-47 */
+        mlp_predict(&L->online, e->fs, L->hp.clip_q, q);
+        if (e->done) q[e->a] = learner_clip_q(L, e->r);
+        else {
+            mlp_predict(&L->online, e->fs2, L->hp.clip_q, qn);
+            const int best = argmax_first(qn, 8);
+            mlp_predict(&L->target, e->fs2, L->hp.clip_q, qt);
+            q[e->a] = learner_clip_q(L, e->r + L->hp.gamma * qt[best]);
+        }
+    }
+    const double loss = mlp_train_batch(&L->online, xs, tg, need, L->hp.grad_clip, L->hp.clip_q, L->hp.lr);
+    if (L->steps % L->hp.target_update_every == 0) mlp_copy(&L->target, &L->online);
+    L->ema = (L->ema == 0.0) ? loss : L->hp.ema_alpha * loss + (1 - L->hp.ema_alpha) * L->ema;
+    free(ix); free(xs); free(tg);
+    return loss;
+}
+/* which: 0 = online, 1 = target.  W1[h*7], b1[h], W2[h*h], b2[h], W3[8*h], b3[8] */
+EXPORT void orc_learner_get_weights(void *h, int32_t which, double *W1, double *b1, double *W2, double *b2, double *W3,
+                                    double *b3) {
+    const learner *L = (const learner *)h;
+    const mlp *m = which ? &L->target : &L->online;
+    memcpy(W1, m->W1, 8 * (size_t)m->h * m->in); memcpy(b1, m->b1, 8 * (size_t)m->h);
+    memcpy(W2, m->W2, 8 * (size_t)m->h * m->h); memcpy(b2, m->b2, 8 * (size_t)m->h);
+    memcpy(W3, m->W3, 8 * (size_t)m->out * m->h); memcpy(b3, m->b3, 8 * (size_t)m->out);
+}
+EXPORT void orc_learner_q_values(void *h, int32_t which, const orc_state *s, double *q) {
+    const learner *L = (const learner *)h;
+    double f[7];
+    orc_features(s, f);
+    mlp_predict(which ? &L->target : &L->online, f, L->hp.clip_q, q);
+}
+EXPORT void orc_mlp_train_batch(int32_t h, double *W1, double *b1, double *W2, double *b2, double *W3, double *b3,
+                                const double *xs, const double *tgts, int32_t n, double grad_clip, double clamp,
+                                double lr, double *loss) {
+    mlp m = {7, h, 8, W1, b1, W2, b2, W3, b3};
+    *loss = mlp_train_batch(&m, xs, tgts, n, grad_clip, clamp, lr);
 }

@@ -65,6 +65,9 @@ def lib():
         L.orc_world_create.restype = C.c_void_p
         L.orc_peak_i.restype = C.c_double
         L.orc_bench_points.restype = C.c_int64
+        L.orc_learner_create.restype = C.c_void_p
+        L.orc_learner_learn.restype = C.c_double
+        L.orc_learner_ema_loss.restype = C.c_double
         _lib = L
     return _lib
 
@@ -140,6 +143,78 @@ def mlp_predict(x, clamp=10.0, n_in=7, h=128, n_out=8):
     y = np.zeros(n_out)
     lib().orc_mlp_predict(n_in, h, n_out, _p(x, C.c_double), C.c_double(clamp), _p(y, C.c_double))
     return y
+
+
+class LearnHyper(C.Structure):
+    """HyperParams fields DDQNAgent.learn reads (config.scala:3-21)."""
+    _fields_ = [("gamma", C.c_double), ("lr", C.c_double), ("clip_q", C.c_double), ("grad_clip", C.c_double),
+                ("ema_alpha", C.c_double), ("hidden", C.c_int32), ("replay_capacity", C.c_int32),
+                ("target_update_every", C.c_int32), ("max_need", C.c_int32)]
+
+
+def default_learn_hyper(**kw):
+    hp = LearnHyper(0.99, 1e-3, 10.0, 1.0, 0.0, 128, 50000, 1500, 512)
+    for k, v in kw.items():
+        setattr(hp, k, v)
+    return hp
+
+
+class Learner:
+    """One DDQNAgent's replay buffer, two networks and learn step (DDQNAgent.scala:6-65)."""
+
+    def __init__(self, hp):
+        self.hp = hp
+        self.h = C.c_void_p(lib().orc_learner_create(C.byref(hp)))
+
+    def close(self):
+        if self.h:
+            lib().orc_learner_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def observe(self, s, a, r, s2, done):
+        lib().orc_learner_observe(self.h, C.byref(s), C.c_int32(int(a)), C.c_double(r), C.byref(s2), C.c_int32(int(done)))
+
+    def replay_size(self):
+        return lib().orc_learner_replay_size(self.h)
+
+    def set_steps(self, steps):
+        lib().orc_learner_set_steps(self.h, C.c_int64(steps))
+
+    def ema_loss(self):
+        return lib().orc_learner_ema_loss(self.h)
+
+    def sample(self, n):
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        k = lib().orc_learner_sample(self.h, C.c_int32(n), _p(out, C.c_int32))
+        return out[:k]
+
+    def learn(self, batch, grad_accum=4):
+        return lib().orc_learner_learn(self.h, C.c_int32(batch), C.c_int32(grad_accum))
+
+    def weights(self, target=False):
+        h = self.hp.hidden
+        W = [np.zeros((h, 7)), np.zeros(h), np.zeros((h, h)), np.zeros(h), np.zeros((8, h)), np.zeros(8)]
+        lib().orc_learner_get_weights(self.h, C.c_int32(1 if target else 0), *[_p(w, C.c_double) for w in W])
+        return W
+
+    def q_values(self, s, target=False):
+        q = np.zeros(8)
+        lib().orc_learner_q_values(self.h, C.c_int32(1 if target else 0), C.byref(s), _p(q, C.c_double))
+        return q
+
+
+def mlp_train_batch(weights, xs, tgts, grad_clip, clamp, lr):
+    """MLP.trainBatch on copies of `weights` = [W1, b1, W2, b2, W3, b3]; returns (new weights, loss)."""
+    W = [np.array(w, dtype=np.float64, order="C", copy=True) for w in weights]
+    xs = np.ascontiguousarray(xs, dtype=np.float64); tgts = np.ascontiguousarray(tgts, dtype=np.float64)
+    loss = C.c_double(0.0)
+    lib().orc_mlp_train_batch(C.c_int32(W[1].shape[0]), *[_p(w, C.c_double) for w in W], _p(xs, C.c_double),
+                              _p(tgts, C.c_double), C.c_int32(xs.shape[0]), C.c_double(grad_clip), C.c_double(clamp),
+                              C.c_double(lr), C.byref(loss))
+    return W, loss.value
 
 
 def scale_row(W, row, factor):

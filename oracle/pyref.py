@@ -328,6 +328,114 @@ class MLP:  # MLP.scala:4-22
         return y
 
 
+    def train_batch(self, xs, tgts, grad_clip, clamp):  # MLP.scala:29-99
+        relu = lambda v: v if v > 0 else 0.0
+        clip = lambda v, c: max(-c, min(c, v)) if math.isfinite(c) else v
+        h, n_in, n_out = len(self.W2), len(self.W1[0]), len(self.W3)
+        gW1 = [[0.0] * n_in for _ in range(h)]; gb1 = [0.0] * h
+        gW2 = [[0.0] * h for _ in range(h)]; gb2 = [0.0] * h
+        gW3 = [[0.0] * h for _ in range(n_out)]; gb3 = [0.0] * n_out
+        loss_sum = 0.0
+        for x0, tgt in zip(xs, tgts):
+            z1 = [s + b for s, b in zip(self._mv(self.W1, x0), self.b1)]; h1 = [relu(z) for z in z1]
+            z2 = [s + b for s, b in zip(self._mv(self.W2, h1), self.b2)]; h2 = [relu(z) for z in z2]
+            y = [s + b for s, b in zip(self._mv(self.W3, h2), self.b3)]
+            yc = [clip(v, clamp) for v in y]
+            err = [p - t for p, t in zip(yc, tgt)]
+            loss_sum += seq_sum(0.5 * e * e for e in err)
+            dh2 = [seq_sum(self.W3[i][j] * err[i] for i in range(n_out)) for j in range(h)]
+            dz2 = [g * relu(z) for g, z in zip(dh2, z2)]
+            dh1 = [seq_sum(self.W2[i][j] * dz2[i] for i in range(h)) for j in range(h)]
+            dz1 = [g * relu(z) for g, z in zip(dh1, z1)]
+            for i in range(n_out):
+                for j in range(h):
+                    gW3[i][j] += err[i] * h2[j]
+                gb3[i] += err[i]
+            for i in range(h):
+                for j in range(h):
+                    gW2[i][j] += dz2[i] * h1[j]
+                gb2[i] += dz2[i]
+                for j in range(n_in):
+                    gW1[i][j] += dz1[i] * x0[j]
+                gb1[i] += dz1[i]
+        scale = 1.0 / max(1, len(xs))
+        lr = self.lr
+        for W, g in ((self.W3, gW3), (self.W2, gW2), (self.W1, gW1)):
+            for i in range(len(W)):
+                for j in range(len(W[i])):
+                    W[i][j] -= lr * clip(g[i][j] * scale, grad_clip)
+        for b, g in ((self.b3, gb3), (self.b2, gb2), (self.b1, gb1)):
+            for i in range(len(b)):
+                b[i] -= lr * clip(g[i] * scale, grad_clip)
+        return loss_sum / max(1, len(xs))
+
+    def copy_from(self, src):  # MLP.scala:101-109
+        for name in ("W1", "W2", "W3"):
+            setattr(self, name, [list(r) for r in getattr(src, name)])
+        for name in ("b1", "b2", "b3"):
+            setattr(self, name, list(getattr(src, name)))
+
+
+class Learner:
+    """DDQNAgent.observe / ddqnTarget / learn with its ReplayBuffer (DDQNAgent.scala:34-65, ReplayBuffer.scala:10-22).
+    hp: gamma, lr, clip_q, grad_clip, ema_alpha, hidden, replay_capacity, target_update_every."""
+
+    def __init__(self, hp):
+        self.hp = hp
+        self.online = MLP(7, hp["hidden"], 8); self.target = MLP(7, hp["hidden"], 8)
+        self.online.lr = self.target.lr = hp["lr"]
+        self.buf = []; self.idx = 0
+        self.rnd = JavaRandom(123)
+        self.steps = 0; self.ema = 0.0
+
+    def observe(self, s, a, r, s2, done):
+        tr = (s.features(), a, r, s2.features(), done)
+        if len(self.buf) < self.hp["replay_capacity"]:
+            self.buf.append(tr)
+        else:
+            self.buf[self.idx] = tr
+            self.idx = (self.idx + 1) % self.hp["replay_capacity"]
+
+    def sample(self, n):  # rnd.shuffle(buf).take(n): scala.util.Random.shuffle, Scala 2.13 library
+        b = list(range(len(self.buf)))
+        for m in range(len(b), 1, -1):
+            k = self.rnd.next_int(m)
+            b[m - 1], b[k] = b[k], b[m - 1]
+        return b[:n]
+
+    def _clip_q(self, x):
+        return max(-self.hp["clip_q"], min(self.hp["clip_q"], x))
+
+    def _target(self, tr):
+        fs, a, r, fs2, done = tr
+        q = list(self.online.predict(fs, self.hp["clip_q"]))
+        if done:
+            q[a] = self._clip_q(r)
+        else:
+            qn = self.online.predict(fs2, self.hp["clip_q"])
+            best = 0
+            for k in range(1, len(qn)):
+                if qn[k] > qn[best]:
+                    best = k
+            qt = self.target.predict(fs2, self.hp["clip_q"])
+            q[a] = self._clip_q(r + self.hp["gamma"] * qt[best])
+        return q
+
+    def learn(self, batch, grad_accum=4):
+        need = max(batch * grad_accum, batch)
+        if len(self.buf) < need:
+            return 0.0
+        micros = [self.buf[k] for k in self.sample(need)]
+        xs = [m[0] for m in micros]
+        tgts = [self._target(m) for m in micros]
+        loss = self.online.train_batch(xs, tgts, self.hp["grad_clip"], self.hp["clip_q"])
+        if self.steps % self.hp["target_update_every"] == 0:
+            self.target.copy_from(self.online)
+        a = self.hp["ema_alpha"]
+        self.ema = loss if self.ema == 0.0 else a * loss + (1 - a) * self.ema
+        return loss
+
+
 _SHARED_MLP = {}
 
 
@@ -355,8 +463,9 @@ class Agent:  # DDQNAgent.scala:6-32 (action choice only)
         return best
 
     def act(self, s):
+        eps = self.epsilon()  # argument of actWithEpsilon: evaluated before countStep raises the counter
         self.steps += 1
-        if self.rnd.next_double() < self.epsilon():
+        if self.rnd.next_double() < eps:
             return self.rnd.next_int(8)
         return self.act_greedy(s)
 

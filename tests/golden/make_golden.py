@@ -37,8 +37,9 @@ def main():
     ag = P.Agent(P.DEFAULT_HP)
     acts = []
     for _ in range(520):
+        eps = ag.epsilon()   # read before the step is counted (DDQNAgent.scala:26-27,32)
         ag.steps += 1
-        acts.append(ag.rnd.next_int(8) if ag.rnd.next_double() < ag.epsilon() else -1)
+        acts.append(ag.rnd.next_int(8) if ag.rnd.next_double() < eps else -1)
     dump("jvm_streams.json", dict(next_int_seed42=ints, next_double_seed42=[d.hex() for d in dbls], gaussians=gauss,
                                   agent_actions=acts))
 

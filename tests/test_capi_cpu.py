@@ -55,6 +55,21 @@ def test_host_streams_match_oracle(epi, oracle):
     assert L.epi_agent_actions(C.byref(hp), 600, acts.ctypes.data_as(C.POINTER(C.c_int32))) == 0
     assert acts[:10].tolist() == [6, 6, 7, 2, 4, 0, 2, 3, 2, 6]
     assert np.flatnonzero(acts < 0)[:2].tolist() == [113, 455]
+    # act(s) passes `epsilon` as an argument: it is read before the call counts the step (DDQNAgent.scala:26-27,32).
+    # With a one-step decay from 1 to 0 the first call still explores, every later one takes argmax Q.
+    from epidemicsimulator_amd import _capi
+    hp1 = _capi.CHyper(1.0, 0.0, 1, 128, 10.0, 5.0, 128, 8)
+    assert L.epi_agent_actions(C.byref(hp1), 5, acts.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+    assert acts[0] >= 0 and (acts[1:5] < 0).all()
+    from oracle import pyref as P
+    ag = P.Agent(dict(P.DEFAULT_HP, epsilon_decay_steps=7, epsilon_end=0.2))
+    hp7 = _capi.CHyper(1.0, 0.2, 7, 128, 10.0, 5.0, 128, 8)
+    assert L.epi_agent_actions(C.byref(hp7), 40, acts.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+    want = []
+    for _ in range(40):
+        eps = ag.epsilon(); ag.steps += 1
+        want.append(ag.rnd.next_int(8) if ag.rnd.next_double() < eps else -1)
+    assert acts[:40].tolist() == want
     W = epi.mlp_init(128)
     for a, b in zip(W, O.mlp_weights()):
         np.testing.assert_array_equal(a, b)

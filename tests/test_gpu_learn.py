@@ -1,0 +1,186 @@
+"""GPU parity of the DDQN learners (epi_agents_*) with the CPU oracle: replay sampling, ddqnTarget,
+MLP.trainBatch, target-network copies.  Bit-exact: weights, Q-values, losses are compared with ==."""
+import numpy as np
+import pytest
+
+from oracle import oracle_lib as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["W1", "b1", "W2", "b2", "W3", "b3"]
+
+
+@pytest.fixture(scope="module")
+def epi():
+    import epidemicsimulator_amd as E
+    assert E.lib().epi_device_count() >= 1, "no HIP device: GPU tests must run on the MI355X box"
+    return E
+
+
+def _state_tuple(rng, t, t_max=60):
+    pop = int(rng.integers(10_000, 50_000_000))
+    i = int(rng.integers(0, max(2, pop // 50))); r = int(rng.integers(0, pop // 10)); d = int(rng.integers(0, pop // 500))
+    v = int(rng.integers(0, pop // 20))
+    return (float(pop - i - r - d), float(i), float(r), float(d), float(v), float(rng.integers(50, 100_000)), int(t), t_max, 1)
+
+
+def _feed(epi, rng, agents, learners, count, ids=None):
+    """`count` random transitions per agent, the same ones into the engine and into the oracle learners."""
+    ids = list(range(len(learners))) if ids is None else ids
+    for k in range(count):
+        trs = []
+        for a in ids:
+            s = _state_tuple(rng, k % 60); s2 = _state_tuple(rng, k % 60 + 1)
+            act = int(rng.integers(0, 8)); r = float(rng.normal() * (12.0 if k % 5 == 0 else 2.0)); done = bool(rng.random() < 0.15)
+            learners[a].observe(O.State(*s, 0), act, r, O.State(*s2, 0), done)
+            trs.append(epi.Transition(epi.State(*s), act, r, epi.State(*s2), done))
+        agents.observe(trs, ids)
+
+
+def _hps(epi, n, **kw):
+    out = []
+    for a in range(n):
+        d = dict(gamma=0.99 - 0.05 * a, lr=1e-3 * (1 + a), clip_q=10.0 - 3.0 * a, grad_clip=1.0 if a != 1 else 0.05,
+                 ema_alpha=0.1 * a, target_update_every=3 + a)
+        d.update(kw)
+        out.append(epi.HyperParams(**d))
+    return out
+
+
+def _oracle_hp(h, max_need):
+    return O.LearnHyper(h.gamma, h.lr, h.clip_q, h.grad_clip, h.ema_alpha, h.hidden, h.replay_capacity,
+                        h.target_update_every, max_need)
+
+
+def _assert_same_networks(agents, learners):
+    for a, L in enumerate(learners):
+        for tgt in (False, True):
+            got, want = agents.weights(a, tgt), L.weights(tgt)
+            for name, g, w in zip(NAMES, got, want):
+                assert np.array_equal(g, w), "agent %d %s %s: max diff %g" % (a, "target" if tgt else "online", name, np.abs(g - w).max())
+
+
+@pytest.mark.parametrize("hidden,batch,accum,capacity,pushes", [
+    (16, 4, 2, 40, 55),        # ring overwritten, tiny network
+    (100, 8, 1, 500, 64),      # width off the 64 grid
+    (128, 128, 4, 50000, 700),  # the reference's defaults: 512 samples per learn
+    (256, 10, 3, 64, 64),      # widest supported, need not a multiple of 4
+])
+def test_learn_matches_oracle(epi, hidden, batch, accum, capacity, pushes):
+    rng = np.random.default_rng(hidden + batch)
+    hps = _hps(epi, 3, hidden=hidden, batch_size=batch, replay_capacity=capacity)
+    agents = epi.Agents(hps, max_grad_accum=accum)
+    learners = [O.Learner(_oracle_hp(h, batch * accum)) for h in hps]
+    _feed(epi, rng, agents, learners, pushes)
+    assert list(agents.replay_size()) == [L.replay_size() for L in learners]
+    _assert_same_networks(agents, learners)
+    steps = [0, 0, 0]
+    for it in range(5):
+        steps = [s + int(rng.integers(1, 4)) for s in steps]
+        ids = [0, 1, 2] if it != 2 else [2, 0]   # a subset, out of order
+        for a in ids:
+            learners[a].set_steps(steps[a])
+        want = [learners[a].learn(batch, accum) for a in ids]
+        loss, ema = agents.learn([steps[a] for a in ids], [batch] * len(ids), accum, ids)
+        assert list(loss) == want, "learn call %d" % it
+        assert list(ema) == [learners[a].ema_loss() for a in ids]
+        assert all(w > 0 for w in want)
+        _feed(epi, rng, agents, learners, 3)
+    _assert_same_networks(agents, learners)
+    probe = [epi.State(*_state_tuple(rng, 7)) for _ in range(3)]
+    for tgt in (False, True):
+        q, g = agents.q_values(probe, target=tgt)
+        for a in range(3):
+            want_q = learners[a].q_values(util.oracle_state(probe[a]), tgt)
+            assert np.array_equal(q[a], want_q)
+            assert g[a] == int(np.argmax(want_q))
+
+
+def test_short_buffer_returns_zero_and_draws_nothing(epi):
+    """DDQNAgent.scala:52-53: learn returns 0.0 before the shuffle while the buffer is short."""
+    rng = np.random.default_rng(5)
+    hps = _hps(epi, 2, hidden=16, batch_size=8, replay_capacity=100)
+    agents = epi.Agents(hps, max_grad_accum=2)
+    learners = [O.Learner(_oracle_hp(h, 16)) for h in hps]
+    _feed(epi, rng, agents, learners, 15)            # 15 < 16
+    _feed(epi, rng, agents, learners, 5, ids=[1])    # agent 1 reaches 20
+    loss, _ = agents.learn([1, 1], [8, 8], 2)
+    for L in learners:
+        L.set_steps(1)
+    want = [L.learn(8, 2) for L in learners]
+    assert loss[0] == 0.0 and want[0] == 0.0 and loss[1] == want[1] > 0
+    # agent 0 drew nothing: its next sample is the first of a fresh Random(123)
+    assert list(agents.sample(0, 15)) == list(learners[0].sample(15))
+    _assert_same_networks(agents, learners)
+    _feed(epi, rng, agents, learners, 20)
+    with pytest.raises(epi.EpiError):
+        agents.learn([2, 2], [8, 8], 4)              # needs 32 samples, the handle was sized for 16
+
+
+def test_replay_buffer_spec(epi):
+    """ReplayBufferSpec.scala:13-35 restated: identical buffers give identical samples; the ring keeps the
+    newest `capacity` transitions."""
+    def mk(i):
+        return epi.State(1000 - i, float(i), 0.0, 0.0, 0.0, 100.0, i, 999, 1)
+
+    def tr(i):
+        return epi.Transition(mk(i), i % 3, float(i), mk(i + 1), False)
+
+    hp = epi.HyperParams(hidden=16, replay_capacity=16, batch_size=4)
+    a = epi.Agents([hp, hp], max_grad_accum=3)
+    for i in range(16):
+        a.observe([tr(i), tr(i)])
+    sa, sb = a.sample(0, 12), a.sample(1, 12)
+    assert len(sa) == 12 and list(sa) == list(sb)
+    ring = epi.Agents([epi.HyperParams(hidden=16, replay_capacity=4, batch_size=1)], max_grad_accum=4)
+    for i in range(8):
+        ring.observe([tr(i)])
+    assert ring.replay_size()[0] == 4
+    # positions 0..3 of the ring now hold transitions 4..7 (ReplayBuffer.scala:16-17)
+    assert sorted(ring.sample(0, 4)) == [0, 1, 2, 3]
+    L = O.Learner(O.default_learn_hyper(hidden=16, replay_capacity=4))
+    for i in range(8):
+        L.observe(util.oracle_state(mk(i)), i % 3, float(i), util.oracle_state(mk(i + 1)), False)
+    fresh = epi.Agents([epi.HyperParams(hidden=16, replay_capacity=4, batch_size=1)], max_grad_accum=4)
+    for i in range(8):
+        fresh.observe([tr(i)])
+    assert list(fresh.sample(0, 4)) == list(L.sample(4))
+    # the stored transitions are the last four: one learn on all four of them matches the oracle's
+    L.set_steps(1)
+    want = L.learn(1, 4)
+    loss, _ = fresh.learn([1], [1], 4)
+    assert loss[0] == want and want > 0
+
+
+def test_ddqn_agent_mirror(epi):
+    """DDQNAgent's own API (act / observe / learn / epsilonNow / qValues) on one agent against the oracle parts."""
+    from oracle import pyref as P
+    rng = np.random.default_rng(11)
+    hp = epi.HyperParams(hidden=32, batch_size=4, replay_capacity=64, epsilon_decay_steps=50, target_update_every=5)
+    ag = epi.DDQNAgent(hp)
+    L = O.Learner(_oracle_hp(hp, 16))
+    rnd = P.JavaRandom(9)
+    steps = 0
+    for k in range(60):
+        s = _state_tuple(rng, k % 60); s2 = _state_tuple(rng, k % 60 + 1)
+        st = epi.State(*s)
+        frac = min(1.0, steps / 50.0)               # epsilon is read before act() counts the step (:26-27,32)
+        eps = 1.0 + (0.1 - 1.0) * frac
+        assert ag.epsilon_now == eps
+        a = ag.act(st)
+        steps += 1
+        if rnd.next_double() < eps:
+            want_a = rnd.next_int(8)
+        else:
+            want_a = int(np.argmax(L.q_values(util.oracle_state(st))))
+        assert a == want_a, "step %d" % k
+        r = float(rng.normal()); done = bool(k % 9 == 0)
+        ag.observe(epi.Transition(st, a, r, epi.State(*s2), done))
+        L.observe(O.State(*s, 0), a, r, O.State(*s2, 0), done)
+        if k % 4 == 3:
+            L.set_steps(steps)
+            assert ag.learn(4, 2) == L.learn(4, 2)
+            assert ag.ema_loss_now == L.ema_loss()
+    assert ag.replay_size == L.replay_size() == 60
+    assert np.array_equal(ag.q_values(epi.State(*s)), L.q_values(O.State(*s, 0)))

@@ -261,3 +261,44 @@ def test_env_step_c_vs_python_random(oracle):
         penv = P.EpidemicEnv(env.base_beta, env.base_gamma, env.base_ifr, env.noise, env.reward_clip, env.risk_factor, pd, 1)
         pn, pr, pdone = penv.step(P.State(st.s, st.i, st.r, st.d, st.v, st.hosp_cap, st.t, st.t_max, 1), act, z)
         assert nxt.tup() == pn.tup() and rew == pr and done == pdone
+
+
+def test_learner_restatements_agree(oracle):
+    """DDQNAgent.learn / MLP.trainBatch / ReplayBuffer (DDQNAgent.scala:34-65, MLP.scala:29-99,
+    ReplayBuffer.scala:10-22): the C restatement and the independently written Python one give the same
+    losses, weights and sample order on a small network with a ring that overflows.  Parity unpinned against
+    a live JVM run; ReplayBufferSpec's two properties are restated below."""
+    hp = O.default_learn_hyper(hidden=12, replay_capacity=40, target_update_every=3, ema_alpha=0.3, grad_clip=0.05)
+    L = O.Learner(hp)
+    PL = P.Learner(dict(gamma=.99, lr=1e-3, clip_q=10.0, grad_clip=0.05, ema_alpha=0.3, hidden=12, replay_capacity=40,
+                        target_update_every=3))
+    rng = np.random.default_rng(1)
+
+    def mk(i):
+        return (float(rng.integers(0, 1e6)), float(rng.integers(0, 1e4)), float(rng.integers(0, 1e4)),
+                float(rng.integers(0, 100)), float(rng.integers(0, 1e4)), 5000.0, int(i % 60), 60, 1)
+    for i in range(55):
+        a, b = mk(i), mk(i + 1)
+        act = int(rng.integers(0, 8)); r = float(rng.normal() * 20); done = (i % 7 == 0)
+        L.observe(O.State(*a, 0), act, r, O.State(*b, 0), done)
+        PL.observe(P.State(*a), act, r, P.State(*b), done)
+    assert L.replay_size() == len(PL.buf) == 40
+    assert L.learn(16, 4) == 0.0 and PL.learn(16, 4) == 0.0      # 40 < 64: nothing drawn
+    for it in range(4):
+        L.set_steps(it * 3 + (it % 2)); PL.steps = it * 3 + (it % 2)
+        assert L.learn(4, 2) == PL.learn(4, 2) > 0
+    for tgt, net in ((False, PL.online), (True, PL.target)):
+        for name, w in zip(["W1", "b1", "W2", "b2", "W3", "b3"], L.weights(tgt)):
+            np.testing.assert_array_equal(np.array(getattr(net, name)), w)
+    assert L.ema_loss() == PL.ema
+    assert list(L.sample(9)) == PL.sample(9)
+    # ReplayBufferSpec.scala:13-35
+    A, B = O.Learner(O.default_learn_hyper(hidden=4, replay_capacity=16)), O.Learner(O.default_learn_hyper(hidden=4, replay_capacity=16))
+    for i in range(16):
+        s, s2 = O.State(1000 - i, i, 0, 0, 0, 100.0, i, 999, 1, 0), O.State(999 - i, i + 1, 0, 0, 0, 100.0, i + 1, 999, 1, 0)
+        A.observe(s, i % 3, float(i), s2, False); B.observe(s, i % 3, float(i), s2, False)
+    assert list(A.sample(12)) == list(B.sample(12))
+    R = O.Learner(O.default_learn_hyper(hidden=4, replay_capacity=4))
+    for i in range(8):
+        R.observe(O.State(1000 - i, i, 0, 0, 0, 100.0, i, 999, 1, 0), 0, 0.0, O.State(999 - i, i + 1, 0, 0, 0, 100.0, i + 1, 999, 1, 0), False)
+    assert R.replay_size() == 4 and sorted(R.sample(4)) == [0, 1, 2, 3]
