@@ -627,12 +627,19 @@ class WorldToy:
         last_a: int = 0
         arrival: int = -1     # first step index with I >= 10 since the last reset (Validation.arrivalTime), -1 = not yet
         peak_i: float = 0.0   # running Validation.peakI
+        agent: Optional["DDQNAgent"] = None   # WorldToy.scala:50; present when the world learns
+        last_learn_step: int = 0
 
     def __init__(self, hp: HyperParams, base: State, seed_idx: int = 0, conn=None,
                  make_env: Callable[[], EpidemicEnv] = lambda: EpidemicEnv(),
                  make_env_for: Optional[Callable[[str, int], EpidemicEnv]] = None, validate: bool = False,
-                 countries: Optional[Sequence[Geo.Country]] = None, batch: int = 1, device: int = 0):
+                 countries: Optional[Sequence[Geo.Country]] = None, batch: int = 1, device: int = 0,
+                 country_hyper_params: Optional[dict] = None, learning: bool = True):
         self.hp, self.base, self.seed_idx, self.validate, self.batch = hp, base, seed_idx, validate, batch
+        self._device = device
+        self.learning = bool(learning) and batch == 1
+        self.g_step = 0
+        self.last_losses: List[Optional[float]] = []
         self.countries = list(countries) if countries is not None else list(ToyConn.C)
         n = self.n = len(self.countries)
         conn = ToyConn.W if conn is None else conn
@@ -662,7 +669,10 @@ class WorldToy:
         self._mlp = None
         self._steps_done = 0
         st0 = self._get_states()
-        self.nodes = [WorldToy.Node(i, c.name, c.pop, envs[i], hp, st0[0][i]) for i, c in enumerate(self.countries)]
+        chp = country_hyper_params or {}
+        self.nodes = [WorldToy.Node(i, c.name, c.pop, envs[i], chp.get(c.name, hp), st0[0][i])
+                      for i, c in enumerate(self.countries)]
+        self._pool = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -786,19 +796,71 @@ class WorldToy:
         if self._mlp is None:
             self.set_mlp(*mlp_init(self.hp.hidden))
 
+    def _ensure_agents(self):
+        """One DDQNAgent per node (WorldToy.scala:49-50) in a shared device handle."""
+        if self._pool is None:
+            self._pool = Agents([nd.hyper_params for nd in self.nodes], max_grad_accum=4, device=self._device)
+            for nd in self.nodes:
+                nd.agent = DDQNAgent(nd.hyper_params, pool=self._pool, index=nd.idx)
+
+    # WorldToy.scala:157-162
+    LEARNING_INTENSITY = {"India": 2, "Japan": 1, "Germany": 1}
+
     def step_one(self, t_max: int) -> List[Tuple[str, State, float]]:
-        """WorldToy.stepOne (:83-170) with never-trained agents: the epsilon-greedy draws follow the
-        JVM streams; the DDQN update itself stays with the trainer and is not part of this engine."""
+        """WorldToy.stepOne (:83-170).  With `learning` (the default for a single world) every node acts through
+        its own DDQNAgent, observes its transition and learns on its own schedule (:147-167), all network
+        arithmetic on the device.  Without it the agents stay untrained and only their epsilon-greedy streams
+        are followed."""
         assert self.batch == 1, "step_one mirrors the single-world API; use step_actions for batches"
-        acts = [ag.next() for ag in self._agents]
-        if any(a < 0 for a in acts):
-            self._ensure_untrained_mlp()
-            _, greedy = mlp_greedy([nd.s for nd in self.nodes], self._mlp, self.hp.clip_q)
-            acts = [int(g) if a < 0 else a for a, g in zip(acts, greedy)]
+        if not self.learning:
+            acts = [ag.next() for ag in self._agents]
+            if any(a < 0 for a in acts):
+                self._ensure_untrained_mlp()
+                _, greedy = mlp_greedy([nd.s for nd in self.nodes], self._mlp, self.hp.clip_q)
+                acts = [int(g) if a < 0 else a for a, g in zip(acts, greedy)]
+            states, r = self.step_actions([acts], None, t_max)
+            return [(nd.name, s, float(rv)) for nd, s, rv in zip(self.nodes, states[0], r[0])]
+        self._ensure_agents()
+        before = [nd.s for nd in self.nodes]
+        acts = [nd.agent.explores(nd.agent.epsilon_now, count_step=True) for nd in self.nodes]   # :88
+        greedy_ids = [k for k, a in enumerate(acts) if a < 0]
+        if greedy_ids:
+            _, g = self._pool.q_values([before[k] for k in greedy_ids], greedy_ids)
+            for k, a in zip(greedy_ids, g):
+                acts[k] = int(a)
         states, r = self.step_actions([acts], None, t_max)
+        ms, mi = self.last_flows()
+        trs = []
+        for k, nd in enumerate(self.nodes):
+            # the post-env.step state the transition holds (:90,99): the returned state without the mobility
+            # flows of :132-136 and with env.step's own clock
+            s3 = states[0][k]
+            s2 = s3.copy(s=s3.s - float(ms[0][k]), i=s3.i - float(mi[0][k]), t=before[k].t + 1)
+            nn = max(1.0, s2.n)
+            done = (s2.t >= s2.t_max) or (s2.i / nn < 1e-5) or (s2.d / nn > 0.02)   # env.scala:137
+            trs.append(Transition(before[k], acts[k], float(r[0][k]), s2, done))
+        self._pool.observe(trs)
+        self.g_step += 1
+        sizes = self._pool.replay_size()
+        due = [nd for nd in self.nodes
+               if self.g_step - nd.last_learn_step >= nd.hyper_params.learn_every
+               and sizes[nd.idx] >= nd.hyper_params.batch_size * 4]
+        self.last_losses = [None] * self.n
+        if due:
+            ids = [nd.idx for nd in due]
+            loss, ema = self._pool.learn([nd.agent.steps for nd in due], [nd.hyper_params.batch_size for nd in due],
+                                         [WorldToy.LEARNING_INTENSITY.get(nd.name, 1) for nd in due], ids)
+            for nd, l, e in zip(due, loss, ema):
+                nd.last_learn_step = self.g_step
+                nd.agent._ema = float(e)
+                self.last_losses[nd.idx] = float(l)
         return [(nd.name, s, float(rv)) for nd, s, rv in zip(self.nodes, states[0], r[0])]
 
     def step_one_greedy(self, t_max: int) -> List[Tuple[str, State, float]]:  # :172-235
+        if self.learning and self._pool is not None:   # every node asks its own, possibly trained, network (:177)
+            _, g = self._pool.q_values([nd.s for nd in self.nodes])
+            states, r = self.step_actions([[int(a) for a in g]], None, t_max)
+            return [(nd.name, s, float(rv)) for nd, s, rv in zip(self.nodes, states[0], r[0])]
         self._ensure_untrained_mlp()
         out = (_capi.CState * (self.batch * self.n))()
         r = np.zeros((self.batch, self.n)); a = np.zeros((self.batch, self.n), dtype=np.int32)

@@ -595,6 +595,8 @@ typedef struct {
     int32_t replay_size;
 } agent;
 
+EXPORT void orc_learner_destroy(void *h);
+
 static double agent_epsilon(const agent *a, const orc_hyper *hp) { /* DDQNAgent.scala:16-19 */
     int32_t den = hp->epsilon_decay_steps > 1 ? hp->epsilon_decay_steps : 1;
     double frac = fmin(1.0, (double)a->steps / (double)den);
@@ -620,6 +622,10 @@ typedef struct {
     int32_t *last_a;
     int32_t err;      /* 0 ok; 1 local mass; 2 world mass; 3 learning would trigger; 4 assertState */
     int32_t err_node, err_t;
+    /* per-node learners (WorldToy.scala:46-65,147-167), present after orc_world_enable_learning */
+    void **learners;
+    int32_t *learn_every, *batch_size, *intensity;
+    int64_t *last_learn;
 } world;
 
 static int64_t sum_state(const orc_state *s) { /* WorldToy.scala:79-80 */
@@ -673,7 +679,12 @@ EXPORT void *orc_world_create(int32_t n, const int32_t *pop, const double *conn,
 EXPORT void orc_world_destroy(void *h) {
     world *w = (world *)h;
     free(w->pop); free(w->conn); free(w->env); free(w->prof); free(w->env_rnd); free(w->agents);
-    free(w->init); free(w->cur); free(w->last_a); mlp_free(&w->net); free(w);
+    free(w->init); free(w->cur); free(w->last_a); mlp_free(&w->net);
+    if (w->learners) {
+        for (int c = 0; c < w->n; c++) orc_learner_destroy(w->learners[c]);
+        free(w->learners); free(w->learn_every); free(w->batch_size); free(w->intensity); free(w->last_learn);
+    }
+    free(w);
 }
 EXPORT void orc_world_get_states(void *h, orc_state *out) {
     world *w = (world *)h; memcpy(out, w->cur, sizeof(orc_state) * (size_t)w->n);
@@ -1125,3 +1136,65 @@ EXPORT void orc_mlp_train_batch(int32_t h, double *W1, double *b1, double *W2, d
     mlp m = {7, h, 8, W1, b1, W2, b2, W3, b3};
     *loss = mlp_train_batch(&m, xs, tgts, n, grad_clip, clamp, lr);
 }
+
+/* ------------------------------------------------------------------------ */
+/* WorldToy.stepOne with its agents learning (WorldToy.scala:83-170): every   */
+/* node owns a DDQNAgent (:50); hp[c], learn_every[c], batch_size[c] come     */
+/* from countryHyperParams (:49), intensity[c] from the name match (:157-162).*/
+/* ------------------------------------------------------------------------ */
+EXPORT void orc_world_enable_learning(void *h, const orc_learn_hyper *hp, const int32_t *learn_every,
+                                      const int32_t *batch_size, const int32_t *intensity) {
+    world *w = (world *)h;
+    int n = w->n;
+    w->learners = (void **)malloc(sizeof(void *) * (size_t)n);
+    w->learn_every = (int32_t *)malloc(4 * (size_t)n); w->batch_size = (int32_t *)malloc(4 * (size_t)n);
+    w->intensity = (int32_t *)malloc(4 * (size_t)n); w->last_learn = (int64_t *)calloc((size_t)n, 8);
+    for (int c = 0; c < n; c++) {
+        w->learners[c] = orc_learner_create(&hp[c]);
+        w->learn_every[c] = learn_every[c]; w->batch_size[c] = batch_size[c]; w->intensity[c] = intensity[c];
+    }
+}
+
+/* losses[c] = what agent.learn returned on this step, or -1 where the node did not learn */
+EXPORT void orc_world_step_learn(void *h, const orc_hyper *hps, int32_t t_max, double *rewards, double *losses) {
+    world *w = (world *)h;
+    int n = w->n;
+    orc_state *local = (orc_state *)malloc(sizeof(orc_state) * (size_t)n);
+    double q[8];
+    for (int c = 0; c < n; c++) {
+        agent *ag = &w->agents[c];
+        learner *L = (learner *)w->learners[c];
+        int a;
+        double eps = agent_epsilon(ag, &hps[c]);          /* :32: argument read before countStep */
+        ag->steps += 1;
+        L->steps = ag->steps;
+        if (jr_next_double(&ag->rnd) < eps) a = jr_next_int_bound(&ag->rnd, 8);
+        else { orc_learner_q_values(L, 0, &w->cur[c], q); a = argmax_first(q, 8); }
+        int64_t tb = sum_state(&w->cur[c]);
+        int32_t done; double r;
+        double g = jr_next_gaussian(&w->env_rnd[c]);
+        orc_env_step(&w->env[c], &w->prof[c], &w->cur[c], a, g, &local[c], &r, &done);
+        w->last_a[c] = a;
+        if (rewards) rewards[c] = r;
+        if (w->validate) {
+            int64_t ta = sum_state(&local[c]);
+            if (ta != tb && w->err == 0) { w->err = 1; w->err_node = c; w->err_t = w->cur[c].t; }
+        }
+        orc_learner_observe(L, &w->cur[c], a, r, &local[c], done); /* :99 */
+    }
+    mobility_apply(w, local, t_max, NULL, NULL);
+    free(local);
+    w->g_step += 1;
+    for (int c = 0; c < n; c++) { /* :150-167 */
+        if (losses) losses[c] = -1.0;
+        if (w->g_step - w->last_learn[c] >= w->learn_every[c]) {
+            learner *L = (learner *)w->learners[c];
+            if (L->size >= w->batch_size[c] * 4) {
+                double loss = orc_learner_learn(L, w->batch_size[c], w->intensity[c]);
+                if (losses) losses[c] = loss;
+                w->last_learn[c] = w->g_step;
+            }
+        }
+    }
+}
+EXPORT void *orc_world_learner(void *h, int32_t c) { return ((world *)h)->learners[c]; }

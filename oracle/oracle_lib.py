@@ -66,6 +66,7 @@ def lib():
         L.orc_peak_i.restype = C.c_double
         L.orc_bench_points.restype = C.c_int64
         L.orc_learner_create.restype = C.c_void_p
+        L.orc_world_learner.restype = C.c_void_p
         L.orc_learner_learn.restype = C.c_double
         L.orc_learner_ema_loss.restype = C.c_double
         _lib = L
@@ -269,6 +270,29 @@ class World:
         r = np.zeros(self.n)
         lib().orc_world_step(self.h, C.c_int32(t_max), C.c_int32(int(greedy)), _p(r, C.c_double))
         return r
+
+    def enable_learning(self, learn_hps, hypers, learn_every, batch_size, intensity):
+        """Per-node DDQN learners (WorldToy.scala:46-65,147-167): LearnHyper and Hyper records per node."""
+        n = self.n
+        self._hypers = (Hyper * n)(*hypers)
+        lh = (LearnHyper * n)(*learn_hps)
+        le = np.ascontiguousarray(learn_every, dtype=np.int32); bs = np.ascontiguousarray(batch_size, dtype=np.int32)
+        it = np.ascontiguousarray(intensity, dtype=np.int32)
+        lib().orc_world_enable_learning(self.h, lh, _p(le, C.c_int32), _p(bs, C.c_int32), _p(it, C.c_int32))
+
+    def step_learn(self, t_max):
+        """WorldToy.stepOne with learning: (rewards[n], losses[n]; -1 where the node did not learn)."""
+        r = np.zeros(self.n); loss = np.zeros(self.n)
+        lib().orc_world_step_learn(self.h, self._hypers, C.c_int32(t_max), _p(r, C.c_double), _p(loss, C.c_double))
+        return r, loss
+
+    def learner(self, c):
+        """Borrowed view of node c's learner (weights / q_values); owned by the world."""
+        L = Learner.__new__(Learner)
+        L.h = C.c_void_p(lib().orc_world_learner(self.h, C.c_int32(c)))
+        L.hp = None
+        L.close = lambda: None
+        return L
 
     def step_given(self, actions, gauss, t_max):
         a = np.ascontiguousarray(actions, dtype=np.int32)

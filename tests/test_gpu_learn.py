@@ -184,3 +184,50 @@ def test_ddqn_agent_mirror(epi):
             assert ag.ema_loss_now == L.ema_loss()
     assert ag.replay_size == L.replay_size() == 60
     assert np.array_equal(ag.q_values(epi.State(*s)), L.q_values(O.State(*s, 0)))
+
+
+def test_world_step_one_with_learning_agents(epi):
+    """WorldToy.stepOne end to end (:83-170) with the agents learning: the toy world with small batches so that
+    the schedule fires early, per-country hyper-parameters (countryHyperParams, :49) and India's doubled
+    intensity (:157-162).  States, rewards, losses and every node's two networks against the oracle world."""
+    base = epi.State(1e6, 0, 0, 0, 0, 10000.0, 0, 400, 1)
+    hp = epi.HyperParams(hidden=32, batch_size=4, learn_every=3, epsilon_decay_steps=40, target_update_every=7,
+                         replay_capacity=30)
+    chp = {"India": epi.HyperParams(hidden=32, batch_size=3, learn_every=2, epsilon_decay_steps=25, lr=5e-3,
+                                    target_update_every=4, replay_capacity=50, ema_alpha=0.2)}
+    w = epi.WorldToy(hp, base, validate=True, country_hyper_params=chp)
+    names = [c.name for c in w.countries]
+    assert "India" in names
+    envs = w._envs
+    ow = O.World([c.pop for c in w.countries], np.asarray(epi.ToyConn.W, dtype=np.float64), 0, util.oracle_state(base),
+                 [O.EnvParams(e.base_beta, e.base_gamma, e.base_ifr, e.noise, e.reward_clip, e.risk_factor) for e in envs],
+                 [util.prof_dict(e.country_profile) for e in envs], [e.seed for e in envs], validate=True)
+    hps = [chp.get(nm, hp) for nm in names]
+    ow.enable_learning([_oracle_hp(h, h.batch_size * 4) for h in hps],
+                       [O.Hyper(h.epsilon_start, h.epsilon_end, h.epsilon_decay_steps, h.hidden, h.clip_q, h.reward_clip,
+                                h.batch_size, h.learn_every) for h in hps],
+                       [h.learn_every for h in hps], [h.batch_size for h in hps],
+                       [2 if nm == "India" else 1 for nm in names])
+    learned = 0
+    for step in range(90):
+        out = w.step_one(400)
+        want_r, want_loss = ow.step_learn(400)
+        assert ow.error()[0] == 0
+        want_s = ow.states()
+        for k, (nm, s, r) in enumerate(out):
+            assert (s.s, s.i, s.r, s.d, s.v, s.hosp_cap, s.t) == want_s[k].tup(), "step %d node %s" % (step, nm)
+            assert r == want_r[k]
+            got_loss = w.last_losses[k]
+            assert (got_loss is None and want_loss[k] == -1.0) or got_loss == want_loss[k], "step %d node %s" % (step, nm)
+            learned += got_loss is not None
+    assert learned > 100
+    for k in range(w.n):
+        L = ow.learner(k)
+        L.hp = _oracle_hp(hps[k], 1)
+        for tgt in (False, True):
+            for name, g, x in zip(NAMES, w._pool.weights(k, tgt), L.weights(tgt)):
+                assert np.array_equal(g, x), "node %d %s" % (k, name)
+    # greedy evaluation now uses the trained networks (:172-235)
+    out = w.step_one_greedy(400)
+    acts = [int(np.argmax(ow.learner(k).q_values(want_s[k]))) for k in range(w.n)]
+    assert [nd.last_a for nd in w.nodes] == acts
