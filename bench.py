@@ -187,6 +187,90 @@ def run_c5(args, rank, local_rank, world, use_dist):
         dist.destroy_process_group()
 
 
+def run_learn(args, rank, local_rank, world, use_dist):
+    """DDQN learn leg (outside the headline metric): `A` independent agents with the reference's default
+    hyper-parameters (hidden 128, batch 128, gradAccumSteps 4 -> 512 samples per learn) each take one
+    DDQNAgent.learn per iteration, all agents in one set of launches.  More GPUs hold more agents (weak)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import epidemicsimulator_amd as E
+
+    A, fill = 192, 2048
+    hp = E.HyperParams()
+    agents = E.Agents([hp] * A, max_grad_accum=4, device=local_rank)
+    rng = np.random.Generator(np.random.PCG64(77 + rank))
+
+    def state():
+        pop = int(rng.integers(10_000, 50_000_000)); i = int(rng.integers(0, pop // 50)); r = int(rng.integers(0, pop // 10))
+        return E.State(float(pop - i - r), float(i), float(r), float(rng.integers(0, pop // 500)), 0.0,
+                       float(rng.integers(50, 100_000)), int(rng.integers(0, 60)), 60, 1)
+
+    pool = [state() for _ in range(256)]
+    for k in range(fill):
+        agents.observe([E.Transition(pool[(k + a) % 256], int(rng.integers(0, 8)), float(rng.normal() * 2), pool[(k + a + 1) % 256],
+                                     bool(k % 11 == 0)) for a in range(A)])
+    need = hp.batch_size * 4
+    flop_per_sample = 2.0 * (3 * (7 * 128 + 128 * 128 + 128 * 8) + 2 * 128 * 128 + 7 * 128 + 3 * 128)
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step = 1
+    for _ in range(args.warmup):
+        agents.learn([step] * A, None, 4); step += 1
+    fence()
+    agents.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        agents.learn([step] * A, None, 4); step += 1
+    fence()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_calls, k_samples = agents.kernel_time()
+    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if use_dist:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    achieved = k_samples * flop_per_sample / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    peak = 78.6 / 2.0   # vector fp64 peak counts an FMA as two flops; this path may not fuse, so one flop per issue slot
+    out = {
+        "metric": "samples/sec (DDQN learn step, whole node)",
+        "value": float(world) * A * need * args.steps / elapsed, "unit": "samples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(1, args.steps) * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "learn: %d agents, hidden 128, %d samples per learn (batch 128 x gradAccumSteps 4), replay of "
+                               "%d transitions each, shuffle on the host" % (A, need, fill),
+                   "agents_per_gpu": A, "parallelism": "independent agents" if world > 1 else "single GPU"},
+        "roofline": {"bound": "valu-fp64 (unfused, ordered sums: neither hbm nor mfma bounds this path)",
+                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                     "kernel": "agents_forward_kernel + agents_backward_kernel + agents_grad_w2_kernel + agents_grad_small_kernel",
+                     "launches": int(k_calls), "avg_launch_ms": k_ms / max(1, k_calls),
+                     "flop_per_sample": flop_per_sample},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle_lib as O
+            L = O.Learner(O.default_learn_hyper())
+            for k in range(fill):
+                a, b = pool[k % 256], pool[(k + 1) % 256]
+                L.observe(O.State(a.s, a.i, a.r, a.d, a.v, a.hosp_cap, a.t, a.t_max, a.seed, 0), int(k % 8), 0.5,
+                          O.State(b.s, b.i, b.r, b.d, b.v, b.hosp_cap, b.t, b.t_max, b.seed, 0), k % 11 == 0)
+            L.set_steps(1)
+            t1 = time.perf_counter(); reps = 0
+            while time.perf_counter() - t1 < 10.0:
+                L.learn(hp.batch_size, 4); reps += 1
+            dt = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": reps * need / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+                                   "sample": "%d learn calls of one agent (512 samples each) in the C oracle" % reps}
+        print(json.dumps(out), flush=True)
+    agents.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,6 +300,8 @@ def main():
 
     if args.workload.lower() == "c5":
         return run_c5(args, rank, local_rank, world, use_dist)
+    if args.workload.lower() == "learn":
+        return run_learn(args, rank, local_rank, world, use_dist)
 
     import epidemicsimulator_amd as E
     from epidemicsimulator_amd import synth

@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "../../include/epi.h"
@@ -31,7 +32,7 @@ namespace {
 constexpr int kIn = 7;        // State.features (env.scala:28-30)
 constexpr int kOut = 8;       // Action.values.length
 constexpr int kXStride = 8;   // features padded to 8 doubles per row
-constexpr int kRows = 4;      // sample rows one workgroup carries through a layer (weights read once for all)
+constexpr int kGradRows = 16; // rows of gW2 one thread accumulates (one read of h1 serves them all)
 constexpr int kMaxHidden = 256;
 
 // One network in device memory, every matrix with row stride Hp (hidden rounded up to 64):
@@ -55,7 +56,7 @@ struct AgentHyperDev {
 // Arguments shared by the kernels of one call.  A "slot" is one agent taking part in the call.
 struct AgentsArgs {
     NetLayout nl;
-    int Bp;                     // row capacity per slot and class (multiple of kRows)
+    int Bp;                     // row capacity per slot and class (multiple of 64)
     int n_classes;              // learn: 3 (s/online, s2/online, s2/target); q-values: 1
     int net_of_class[3];        // 0 = online, 1 = target
     int x_of_class[3];          // which staged feature block the class reads (0 = s, 1 = s2)
@@ -73,6 +74,9 @@ struct AgentsArgs {
     double* DZ2;                // [slots][Bp][Hp]
     double* DZ1;                // [slots][Bp][Hp]
     double* ERR;                // [slots][Bp]  yC(a) - target(a)
+    double* X0d;                // [slots][Bp][kXStride] device copy of the s features (the staged rows sit in host
+    int32_t* ACTd;              // [slots][Bp]           memory: each is read over the bus once, by the first kernel
+                                //                       that needs it, and kept here for the gradient kernels)
     double* loss;               // [slots]
 };
 
@@ -81,102 +85,139 @@ __device__ inline double* net_ptr(const AgentsArgs& a, int agent, int which) {
 }
 __device__ inline double clip_sym(double v, double c) { return isfinite(c) ? fmax(-c, fmin(c, v)) : v; }
 
-// MLP.predict (MLP.scala:15-22) for kRows rows of one class of one slot.  Block = Hp threads, thread i owns
-// hidden unit i.  matVec sums left to right starting from the first product.
-__global__ void __launch_bounds__(kMaxHidden) agents_forward_kernel(AgentsArgs a) {
-    __shared__ double sh_x[kRows][kXStride];
-    __shared__ __align__(16) double sh_h[kMaxHidden][kRows];  // [unit][row]: one read brings all rows of a unit
-    const int slot = blockIdx.y, B = a.slot_rows[slot];
-    const int groups = a.Bp / kRows;
-    const int cls = blockIdx.x / groups, k0 = (blockIdx.x % groups) * kRows;
-    if (k0 >= B) return;
-    const int H = a.nl.H, Hp = a.nl.Hp, i = threadIdx.x;
-    const int agent = a.slot_agent[slot];
-    const double* net = net_ptr(a, agent, a.net_of_class[cls]);
-    const double clip_q = a.hyper[agent].clip_q;
-    const double* X = a.X + (((size_t)slot * 2 + a.x_of_class[cls]) * a.Bp + k0) * kXStride;
-    if (i < kRows * kXStride) sh_x[i / kXStride][i % kXStride] = (k0 + i / kXStride < B) ? X[i] : 0.0;
-    __syncthreads();
-    double h[kRows];
-    if (i < H) {
-        const double* W1t = net + a.nl.w1t();
-        double acc[kRows];
-        const double w0 = W1t[i];
-#pragma unroll
-        for (int r = 0; r < kRows; ++r) acc[r] = w0 * sh_x[r][0];
-#pragma unroll
-        for (int j = 1; j < kIn; ++j) {
-            const double w = W1t[(size_t)j * Hp + i];
-#pragma unroll
-            for (int r = 0; r < kRows; ++r) acc[r] = acc[r] + w * sh_x[r][j];
-        }
-        const double b = net[a.nl.b1() + i];
-#pragma unroll
-        for (int r = 0; r < kRows; ++r) {
-            const double z = acc[r] + b;
-            h[r] = z > 0 ? z : 0.0;
-            sh_h[i][r] = h[r];
-            if (cls == 0 && k0 + r < B) a.H1[((size_t)slot * a.Bp + k0 + r) * Hp + i] = h[r];
-        }
-    }
-    __syncthreads();
-    if (i < H) {
-        const double* W2t = net + a.nl.w2t();
-        double acc[kRows];
-        const double w0 = W2t[i];
-#pragma unroll
-        for (int r = 0; r < kRows; ++r) acc[r] = w0 * sh_h[0][r];
-        for (int j = 1; j < H; ++j) {
-            const double w = W2t[(size_t)j * Hp + i];
-#pragma unroll
-            for (int r = 0; r < kRows; ++r) acc[r] = acc[r] + w * sh_h[j][r];
-        }
-        const double b = net[a.nl.b2() + i];
-#pragma unroll
-        for (int r = 0; r < kRows; ++r) {
-            const double z = acc[r] + b;
-            h[r] = z > 0 ? z : 0.0;
-            if (cls == 0 && k0 + r < B) a.H2[((size_t)slot * a.Bp + k0 + r) * Hp + i] = h[r];
-        }
-    }
-    __syncthreads();  // every thread has finished reading the first hidden layer
-    if (i < H) {
-#pragma unroll
-        for (int r = 0; r < kRows; ++r) sh_h[i][r] = h[r];
-    }
-    __syncthreads();
-    if (i < kOut * kRows) {
-        const int o = i % kOut, r = i / kOut;
-        if (k0 + r < B) {
-            const double* W3 = net + a.nl.w3() + (size_t)o * Hp;
-            double acc = W3[0] * sh_h[0][r];
-            for (int j = 1; j < H; ++j) acc = acc + W3[j] * sh_h[j][r];
-            const double y = acc + net[a.nl.b3() + o];
-            a.Q[(((size_t)slot * 3 + cls) * a.Bp + k0 + r) * kOut + o] = clip_sym(y, clip_q);
-        }
+// Tiling of the forward and backward kernels: one lane per sample row (64 rows per workgroup), one wave per
+// tile of kTile hidden units.  A lane multiplies ITS activation by weights that are the same for the whole wave,
+// so the weights arrive through scalar loads (kTile contiguous doubles per step of the sum) and the vector ALU
+// does nothing but the ordered multiply-adds; activations sit in LDS as [unit][row], row stride kLS (odd, so the
+// row-major copies to and from global memory are conflict-free too).
+constexpr int kTileRows = 64;
+constexpr int kTile = 16;
+constexpr int kLS = kTileRows + 1;
+
+__host__ __device__ inline size_t tile_lds_bytes(int Hp) { return ((size_t)Hp * kLS + (size_t)kXStride * kTileRows) * sizeof(double); }
+
+// sh[unit][row] -> dst[row][unit] (row-major, stride Hp) for the rows of the tile that exist
+__device__ inline void store_rows(const double* sh, double* dst, int H, int Hp, int rows) {
+    for (int idx = threadIdx.x; idx < kTileRows * Hp; idx += blockDim.x) {
+        const int row = idx / Hp, unit = idx - row * Hp;
+        if (row < rows && unit < H) dst[(size_t)row * Hp + unit] = sh[unit * kLS + row];
     }
 }
 
-// ddqnTarget (DDQNAgent.scala:37-47) and the backward pass of MLP.trainBatch (MLP.scala:44-58) for kRows
+// acc[u] = sum over j < K, in order, of W[j * ldw + u] * act[j * kLS] (first product starts the sum, as .sum does)
+__device__ inline void ordered_tile(const double* __restrict__ W, int ldw, const double* act, int K, double (&acc)[kTile]) {
+    double h = act[0];
+#pragma unroll
+    for (int u = 0; u < kTile; ++u) acc[u] = W[u] * h;
+#pragma unroll 2
+    for (int j = 1; j < K; ++j) {
+        h = act[j * kLS];
+#pragma unroll
+        for (int u = 0; u < kTile; ++u) acc[u] = acc[u] + W[(size_t)j * ldw + u] * h;
+    }
+}
+
+// MLP.predict (MLP.scala:15-22) for 64 rows of one class of one slot.  matVec sums left to right.
+// `nets` is the same memory as a.nets, passed as a parameter of its own that nothing is stored through: that lets
+// the compiler prove the weights unclobbered and fetch them with scalar loads.
+__global__ void __launch_bounds__(1024) agents_forward_kernel(AgentsArgs a, const double* __restrict__ nets) {
+    extern __shared__ double smem[];
+    double* sh_x = smem;                          // [kXStride][64]
+    double* sh_h = smem + kXStride * kTileRows;   // [Hp][kLS]
+    const int slot = blockIdx.y, B = a.slot_rows[slot];
+    const int groups = a.Bp / kTileRows;
+    const int cls = blockIdx.x / groups, k0 = (blockIdx.x % groups) * kTileRows;
+    if (k0 >= B) return;
+    const int H = a.nl.H, Hp = a.nl.Hp;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i0 = wave * kTile;
+    const int agent = a.slot_agent[slot];
+    const double* __restrict__ net = nets + ((size_t)agent * 2 + a.net_of_class[cls]) * a.nl.size();
+    const double clip_q = a.hyper[agent].clip_q;
+    const int rows = min(kTileRows, B - k0);
+    const size_t row0 = (size_t)slot * a.Bp + k0;
+    const double* X = a.X + (((size_t)slot * 2 + a.x_of_class[cls]) * a.Bp + k0) * kXStride;
+    for (int idx = threadIdx.x; idx < kTileRows * kXStride; idx += blockDim.x) {
+        const int row = idx / kXStride, j = idx % kXStride;
+        const double x = row < rows ? X[idx] : 0.0;   // staged rows sit in host memory: read once, kept on the device
+        sh_x[j * kTileRows + row] = x;
+        if (cls == 0) a.X0d[row0 * kXStride + idx] = x;
+    }
+    __syncthreads();
+    double acc[kTile];
+    if (i0 < H) {
+        const double* __restrict__ W1t = net + a.nl.w1t() + i0;
+        double x = sh_x[lane];
+#pragma unroll
+        for (int u = 0; u < kTile; ++u) acc[u] = W1t[u] * x;
+#pragma unroll
+        for (int j = 1; j < kIn; ++j) {
+            x = sh_x[j * kTileRows + lane];
+#pragma unroll
+            for (int u = 0; u < kTile; ++u) acc[u] = acc[u] + W1t[(size_t)j * Hp + u] * x;
+        }
+        const double* __restrict__ b1 = net + a.nl.b1() + i0;
+#pragma unroll
+        for (int u = 0; u < kTile; ++u) {
+            const double z = acc[u] + b1[u];
+            sh_h[(i0 + u) * kLS + lane] = z > 0 ? z : 0.0;
+        }
+    }
+    __syncthreads();
+    if (cls == 0) store_rows(sh_h, a.H1 + row0 * Hp, H, Hp, rows);
+    if (i0 < H) {
+        ordered_tile(net + a.nl.w2t() + i0, Hp, sh_h + lane, H, acc);
+        const double* __restrict__ b2 = net + a.nl.b2() + i0;
+#pragma unroll
+        for (int u = 0; u < kTile; ++u) {
+            const double z = acc[u] + b2[u];
+            acc[u] = z > 0 ? z : 0.0;
+        }
+    }
+    __syncthreads();  // every wave has finished reading the first hidden layer
+    if (i0 < H) {
+#pragma unroll
+        for (int u = 0; u < kTile; ++u) sh_h[(i0 + u) * kLS + lane] = acc[u];
+    }
+    __syncthreads();
+    if (cls == 0) store_rows(sh_h, a.H2 + row0 * Hp, H, Hp, rows);
+    const int n_waves = blockDim.x >> 6;
+    for (int o = wave; o < kOut; o += n_waves) {
+        const double* __restrict__ W3 = net + a.nl.w3() + (size_t)o * Hp;
+        double y = W3[0] * sh_h[lane];
+#pragma unroll 4
+        for (int j = 1; j < H; ++j) y = y + W3[j] * sh_h[j * kLS + lane];
+        y = y + net[a.nl.b3() + o];
+        if (lane < rows) a.Q[(((size_t)slot * 3 + cls) * a.Bp + k0 + lane) * kOut + o] = clip_sym(y, clip_q);
+    }
+}
+
+// ddqnTarget (DDQNAgent.scala:37-47) and the backward pass of MLP.trainBatch (MLP.scala:44-58) for 64
 // samples.  The target equals the prediction in every component but the action taken, so err is zero there
 // and dh2(j) = W3(a)(j) * err(a).  dz = dh * relu(z) -- the activation's value, as the reference has it.
-__global__ void __launch_bounds__(kMaxHidden) agents_backward_kernel(AgentsArgs a) {
-    __shared__ __align__(16) double sh_dz[kMaxHidden][kRows];
-    __shared__ double sh_err[kRows];
+__global__ void __launch_bounds__(1024) agents_backward_kernel(AgentsArgs a, const double* __restrict__ nets) {
+    extern __shared__ double smem[];
+    double* sh_err = smem;                        // [64]
+    int* sh_act = reinterpret_cast<int*>(smem + kTileRows);  // [64]
+    double* sh_d = smem + kXStride * kTileRows;   // [Hp][kLS]
     const int slot = blockIdx.y, B = a.slot_rows[slot];
-    const int k0 = blockIdx.x * kRows;
+    const int k0 = blockIdx.x * kTileRows;
     if (k0 >= B) return;
-    const int H = a.nl.H, Hp = a.nl.Hp, j = threadIdx.x;
+    const int H = a.nl.H, Hp = a.nl.Hp;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i0 = wave * kTile;
     const int agent = a.slot_agent[slot];
-    const double* net = net_ptr(a, agent, 0);
+    const double* __restrict__ net = nets + (size_t)agent * 2 * a.nl.size();
     const AgentHyperDev hp = a.hyper[agent];
-    if (j < kRows) {
-        const int k = k0 + j;
+    const int rows = min(kTileRows, B - k0);
+    const size_t row0 = (size_t)slot * a.Bp + k0;
+    if (threadIdx.x < kTileRows) {
+        const int k = k0 + lane;
         double err = 0.0;
-        if (k < B) {
-            const size_t row = (size_t)slot * a.Bp + k;
+        int act = 0;
+        if (lane < rows) {
+            const size_t row = row0 + lane;
             const double* q = a.Q + (((size_t)slot * 3 + 0) * a.Bp + k) * kOut;
-            const int act = a.act[row];
+            act = a.act[row];
+            a.ACTd[row] = act;
             double tgt;
             if (a.done[row]) {
                 tgt = fmax(-hp.clip_q, fmin(hp.clip_q, a.rew[row]));
@@ -191,65 +232,67 @@ __global__ void __launch_bounds__(kMaxHidden) agents_backward_kernel(AgentsArgs 
             err = q[act] - tgt;
             a.ERR[row] = err;
         }
-        sh_err[j] = err;
+        sh_err[lane] = err;
+        sh_act[lane] = act;
+    }
+    // second hidden layer's activations of the tile, [unit][row]
+    for (int idx = threadIdx.x; idx < kTileRows * Hp; idx += blockDim.x) {
+        const int row = idx / Hp, unit = idx - row * Hp;
+        sh_d[unit * kLS + row] = row < rows ? a.H2[(row0 + row) * Hp + unit] : 0.0;
     }
     __syncthreads();
-    if (j < H) {
+    if (i0 < H) {
+        const double err = sh_err[lane];
+        const double* W3a = net + a.nl.w3() + (size_t)sh_act[lane] * Hp + i0;
 #pragma unroll
-        for (int r = 0; r < kRows; ++r) {
-            double dz = 0.0;
-            if (k0 + r < B) {
-                const size_t row = (size_t)slot * a.Bp + k0 + r;
-                const double dh = net[a.nl.w3() + (size_t)a.act[row] * Hp + j] * sh_err[r];
-                dz = dh * a.H2[row * Hp + j];
-                a.DZ2[row * Hp + j] = dz;
-            }
-            sh_dz[j][r] = dz;
+        for (int u = 0; u < kTile; ++u) {
+            const double dh = W3a[u] * err;
+            sh_d[(i0 + u) * kLS + lane] = lane < rows ? dh * sh_d[(i0 + u) * kLS + lane] : 0.0;
         }
     }
     __syncthreads();
-    if (j < H) {
-        const double* W2 = net + a.nl.w2();
-        double acc[kRows];
-        const double w0 = W2[j];
+    store_rows(sh_d, a.DZ2 + row0 * Hp, H, Hp, rows);
+    double acc[kTile];
+    if (i0 < H) ordered_tile(net + a.nl.w2() + i0, Hp, sh_d + lane, H, acc);  // dh1(j) = sum_i W2(i)(j) * dz2(i)
+    __syncthreads();  // every wave has finished reading dz2
+    if (i0 < H) {
 #pragma unroll
-        for (int r = 0; r < kRows; ++r) acc[r] = w0 * sh_dz[0][r];
-        for (int i = 1; i < H; ++i) {
-            const double w = W2[(size_t)i * Hp + j];
-#pragma unroll
-            for (int r = 0; r < kRows; ++r) acc[r] = acc[r] + w * sh_dz[i][r];
+        for (int u = 0; u < kTile; ++u) sh_d[(i0 + u) * kLS + lane] = acc[u];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < kTileRows * Hp; idx += blockDim.x) {
+        const int row = idx / Hp, unit = idx - row * Hp;
+        if (row < rows && unit < H) {
+            const size_t g = (row0 + row) * Hp + unit;
+            a.DZ1[g] = sh_d[unit * kLS + row] * a.H1[g];
         }
-#pragma unroll
-        for (int r = 0; r < kRows; ++r)
-            if (k0 + r < B) {
-                const size_t row = (size_t)slot * a.Bp + k0 + r;
-                a.DZ1[row * Hp + j] = acc[r] * a.H1[row * Hp + j];
-            }
     }
 }
 
 // gW2(i)(j) = sum over samples, in sample order, of dz2(i) * h1(j) (MLP.scala:53,66), then mean, clip and
-// the SGD step (:78-93).  Block = Hp threads (j), kRows output rows i per block.  Both layouts are rewritten.
+// the SGD step (:78-93).  Block = Hp threads (j), kGradRows output rows i per block: per sample one coalesced
+// read of h1 and one block-uniform read of kGradRows entries of dz2.  Both layouts of W2 are rewritten.
 __global__ void __launch_bounds__(kMaxHidden) agents_grad_w2_kernel(AgentsArgs a) {
     const int slot = blockIdx.y, B = a.slot_rows[slot];
-    const int H = a.nl.H, Hp = a.nl.Hp, j = threadIdx.x, i0 = blockIdx.x * kRows;
+    const int H = a.nl.H, Hp = a.nl.Hp, j = threadIdx.x, i0 = blockIdx.x * kGradRows;
     if (j >= H || i0 >= H) return;
     const int agent = a.slot_agent[slot];
     double* net = net_ptr(a, agent, 0);
     const AgentHyperDev hp = a.hyper[agent];
-    const double* H1 = a.H1 + (size_t)slot * a.Bp * Hp;
-    const double* DZ2 = a.DZ2 + (size_t)slot * a.Bp * Hp;
-    double acc[kRows];
+    const double* __restrict__ H1 = a.H1 + (size_t)slot * a.Bp * Hp + j;
+    const double* __restrict__ DZ2 = a.DZ2 + (size_t)slot * a.Bp * Hp + i0;  // columns past H hold zeros
+    double acc[kGradRows];
 #pragma unroll
-    for (int r = 0; r < kRows; ++r) acc[r] = 0.0;
+    for (int r = 0; r < kGradRows; ++r) acc[r] = 0.0;
+#pragma unroll 2
     for (int k = 0; k < B; ++k) {
-        const double h = H1[(size_t)k * Hp + j];
+        const double h = H1[(size_t)k * Hp];
 #pragma unroll
-        for (int r = 0; r < kRows; ++r) acc[r] += DZ2[(size_t)k * Hp + i0 + r] * h;  // rows past H hold zeros
+        for (int r = 0; r < kGradRows; ++r) acc[r] += DZ2[(size_t)k * Hp + r] * h;
     }
     const double scale = 1.0 / (double)(B > 1 ? B : 1);
 #pragma unroll
-    for (int r = 0; r < kRows; ++r) {
+    for (int r = 0; r < kGradRows; ++r) {
         const int i = i0 + r;
         if (i < H) {
             const double g = clip_sym(acc[r] * scale, hp.grad_clip);
@@ -260,8 +303,26 @@ __global__ void __launch_bounds__(kMaxHidden) agents_grad_w2_kernel(AgentsArgs a
     }
 }
 
+// Sum of term(0) .. term(B-1) in that order, starting from +0.0.  The terms of a group are formed first (their
+// loads are independent and overlap), then added one after the other.
+template <class F>
+__device__ inline double ordered_sum(int B, F term) {
+    constexpr int G = 16;
+    double acc = 0.0;
+    int k = 0;
+    for (; k + G <= B; k += G) {
+        double v[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) v[u] = term(k + u);
+#pragma unroll
+        for (int u = 0; u < G; ++u) acc += v[u];
+    }
+    for (; k < B; ++k) acc += term(k);
+    return acc;
+}
+
 // The remaining gradients, one thread per parameter, summed in sample order (MLP.scala:49-72), then mean,
-// clip, SGD (:78-96); the last thread forms the batch loss (:46,98).
+// clip, SGD (:78-96); one more thread forms the batch loss (:46,98).
 __global__ void __launch_bounds__(256) agents_grad_small_kernel(AgentsArgs a) {
     const int slot = blockIdx.y, B = a.slot_rows[slot];
     const int H = a.nl.H, Hp = a.nl.Hp;
@@ -269,35 +330,35 @@ __global__ void __launch_bounds__(256) agents_grad_small_kernel(AgentsArgs a) {
     double* net = net_ptr(a, agent, 0);
     const AgentHyperDev hp = a.hyper[agent];
     const size_t base = (size_t)slot * a.Bp;
-    const double* X0 = a.X + ((size_t)slot * 2 + 0) * a.Bp * kXStride;
+    const double* __restrict__ X0 = a.X0d + base * kXStride;
+    const double* __restrict__ DZ1 = a.DZ1 + base * Hp;
+    const double* __restrict__ DZ2 = a.DZ2 + base * Hp;
+    const double* __restrict__ H2 = a.H2 + base * Hp;
+    const double* __restrict__ ERR = a.ERR + base;
+    const int32_t* __restrict__ act = a.ACTd + base;
     const double scale = 1.0 / (double)(B > 1 ? B : 1);
     int e = blockIdx.x * blockDim.x + threadIdx.x;
-    double acc = 0.0;
+    double acc;
     size_t dst;
     if (e < H * kIn) {  // gW1(i)(j) += dz1(i) * x(j)
         const int i = e % H, j = e / H;
-        for (int k = 0; k < B; ++k) acc += a.DZ1[(base + k) * Hp + i] * X0[(size_t)k * kXStride + j];
+        acc = ordered_sum(B, [&](int k) { return DZ1[(size_t)k * Hp + i] * X0[(size_t)k * kXStride + j]; });
         dst = a.nl.w1t() + (size_t)j * Hp + i;
     } else if ((e -= H * kIn) < H) {  // gb1
-        for (int k = 0; k < B; ++k) acc += a.DZ1[(base + k) * Hp + e];
+        acc = ordered_sum(B, [&](int k) { return DZ1[(size_t)k * Hp + e]; });
         dst = a.nl.b1() + e;
     } else if ((e -= H) < H) {  // gb2
-        for (int k = 0; k < B; ++k) acc += a.DZ2[(base + k) * Hp + e];
+        acc = ordered_sum(B, [&](int k) { return DZ2[(size_t)k * Hp + e]; });
         dst = a.nl.b2() + e;
-    } else if ((e -= H) < kOut * H) {  // gW3(o)(j) += err(o) * h2(j): err is zero except at the action taken
-        const int j = e % H, o = e / H;
-        for (int k = 0; k < B; ++k)
-            if (a.act[base + k] == o) acc += a.ERR[base + k] * a.H2[(base + k) * Hp + j];
+    } else if ((e -= H) < kOut * H) {  // gW3(o)(j) += err(o) * h2(j): err is +0.0 except at the action taken,
+        const int j = e % H, o = e / H;  // and adding +0.0 leaves a sum as it is
+        acc = ordered_sum(B, [&](int k) { return act[k] == o ? ERR[k] * H2[(size_t)k * Hp + j] : 0.0; });
         dst = a.nl.w3() + (size_t)o * Hp + j;
     } else if ((e -= kOut * H) < kOut) {  // gb3
-        for (int k = 0; k < B; ++k)
-            if (a.act[base + k] == e) acc += a.ERR[base + k];
+        acc = ordered_sum(B, [&](int k) { return act[k] == e ? ERR[k] : 0.0; });
         dst = a.nl.b3() + e;
     } else if (e == kOut) {  // lossSum / n
-        for (int k = 0; k < B; ++k) {
-            const double er = a.ERR[base + k];
-            acc += 0.5 * er * er;
-        }
+        acc = ordered_sum(B, [&](int k) { return 0.5 * ERR[k] * ERR[k]; });
         a.loss[slot] = acc / (double)(B > 1 ? B : 1);
         return;
     } else {
@@ -351,7 +412,7 @@ struct epi_agents {
     std::vector<epi_learn_hyper> hp;
     std::vector<Replay> replay;
     std::vector<double> ema;
-    DevBuf nets, hyper, H1, H2, Q, DZ2, DZ1, ERR;
+    DevBuf nets, hyper, H1, H2, Q, DZ2, DZ1, ERR, X0d, ACTd;
     PinBuf slot_agent, slot_rows, X, act, rew, done, loss;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -371,7 +432,8 @@ struct epi_agents {
         a.X = X.on_device<double>(); a.act = act.on_device<int32_t>(); a.rew = rew.on_device<double>();
         a.done = done.on_device<int32_t>();
         a.H1 = H1.as<double>(); a.H2 = H2.as<double>(); a.Q = Q.as<double>(); a.DZ2 = DZ2.as<double>();
-        a.DZ1 = DZ1.as<double>(); a.ERR = ERR.as<double>(); a.loss = loss.on_device<double>();
+        a.DZ1 = DZ1.as<double>(); a.ERR = ERR.as<double>(); a.X0d = X0d.as<double>(); a.ACTd = ACTd.as<int32_t>();
+        a.loss = loss.on_device<double>();
         return a;
     }
 };
@@ -429,7 +491,7 @@ EPI_API epi_agents* epi_agents_create(int32_t n_agents, const epi_learn_hyper* h
     std::unique_ptr<epi_agents> g(new epi_agents);
     g->device = device; g->n = n_agents;
     g->nl.H = H; g->nl.Hp = (H + 63) / 64 * 64;
-    g->Bp = (max_need + kRows - 1) / kRows * kRows;
+    g->Bp = (max_need + kTileRows - 1) / kTileRows * kTileRows;
     g->hp.assign(hp, hp + n_agents);
     g->replay.resize((size_t)n_agents);
     g->ema.assign((size_t)n_agents, 0.0);
@@ -450,11 +512,14 @@ EPI_API epi_agents* epi_agents_create(int32_t n_agents, const epi_learn_hyper* h
         !ok(g->H1.ensure(rows * Hp * 8), "H1") || !ok(g->H2.ensure(rows * Hp * 8), "H2") ||
         !ok(g->Q.ensure(rows * 3 * kOut * 8), "Q") || !ok(g->DZ2.ensure(rows * Hp * 8), "DZ2") ||
         !ok(g->DZ1.ensure(rows * Hp * 8), "DZ1") || !ok(g->ERR.ensure(rows * 8), "ERR") ||
+        !ok(g->X0d.ensure(rows * kXStride * 8), "X0d") || !ok(g->ACTd.ensure(rows * 4), "ACTd") ||
         !ok(g->slot_agent.ensure((size_t)n_agents * 4), "slots") || !ok(g->slot_rows.ensure((size_t)n_agents * 4), "slots") ||
         !ok(g->X.ensure(rows * 2 * kXStride * 8), "X") || !ok(g->act.ensure(rows * 4), "act") ||
         !ok(g->rew.ensure(rows * 8), "rew") || !ok(g->done.ensure(rows * 4), "done") ||
         !ok(g->loss.ensure((size_t)n_agents * 8), "loss") ||
         !ok(hipMemset(g->DZ2.p, 0, rows * Hp * 8), "clear") ||  // columns past H are read by the gradient kernel
+        !ok(hipFuncSetAttribute(reinterpret_cast<const void*>(agents_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(g->nl.Hp)), "lds") ||
+        !ok(hipFuncSetAttribute(reinterpret_cast<const void*>(agents_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(g->nl.Hp)), "lds") ||
         !ok(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking), "stream") ||
         !ok(hipEventCreate(&g->ev0), "event") || !ok(hipEventCreate(&g->ev1), "event"))
         return nullptr;
@@ -522,9 +587,10 @@ EPI_API int32_t epi_agents_learn(epi_agents* g, const int32_t* ids, int32_t coun
     }
     if (slots > 0) {
         const int Bp = g->Bp;
-        for (int k = 0; k < count; ++k) {
-            if (slot_of[k] < 0) continue;
-            const int sl = slot_of[k], id = sa[sl], need = sr[sl];
+        // The shuffle walks the whole buffer with a sequential generator (ReplayBuffer.scala:21-22): agents are
+        // independent, so their shuffles and row gathers run on a few host threads.
+        auto stage = [&](int sl) {
+            const int id = sa[sl], need = sr[sl];
             Replay& rp = g->replay[id];
             const int32_t* p = rp.sample();
             double* X0 = g->X.as<double>() + ((size_t)sl * 2 + 0) * Bp * kXStride;
@@ -537,6 +603,15 @@ EPI_API int32_t epi_agents_learn(epi_agents* g, const int32_t* ids, int32_t coun
                 g->rew.as<double>()[(size_t)sl * Bp + q] = t.r;
                 g->done.as<int32_t>()[(size_t)sl * Bp + q] = t.done;
             }
+        };
+        const int n_threads = std::max(1, std::min({slots / 4, 16, (int)std::thread::hardware_concurrency()}));
+        if (n_threads == 1) {
+            for (int sl = 0; sl < slots; ++sl) stage(sl);
+        } else {
+            std::vector<std::thread> pool;
+            for (int th = 0; th < n_threads; ++th)
+                pool.emplace_back([&, th] { for (int sl = th; sl < slots; sl += n_threads) stage(sl); });
+            for (auto& th : pool) th.join();
         }
         AgentsArgs a = g->args();
         a.n_classes = 3;
@@ -544,9 +619,11 @@ EPI_API int32_t epi_agents_learn(epi_agents* g, const int32_t* ids, int32_t coun
         a.x_of_class[0] = 0; a.x_of_class[1] = 1; a.x_of_class[2] = 1;
         const int Hp = g->nl.Hp, H = g->nl.H;
         if (g->timing) HIP_TRY(hipEventRecord(g->ev0, g->stream));
-        hipLaunchKernelGGL(agents_forward_kernel, dim3(3 * Bp / kRows, slots), dim3(Hp), 0, g->stream, a);
-        hipLaunchKernelGGL(agents_backward_kernel, dim3(Bp / kRows, slots), dim3(Hp), 0, g->stream, a);
-        hipLaunchKernelGGL(agents_grad_w2_kernel, dim3((H + kRows - 1) / kRows, slots), dim3(Hp), 0, g->stream, a);
+        const int tile_threads = Hp / kTile * 64;
+        const size_t lds = tile_lds_bytes(Hp);
+        hipLaunchKernelGGL(agents_forward_kernel, dim3(3 * Bp / kTileRows, slots), dim3(tile_threads), lds, g->stream, a, a.nets);
+        hipLaunchKernelGGL(agents_backward_kernel, dim3(Bp / kTileRows, slots), dim3(tile_threads), lds, g->stream, a, a.nets);
+        hipLaunchKernelGGL(agents_grad_w2_kernel, dim3((H + kGradRows - 1) / kGradRows, slots), dim3(Hp), 0, g->stream, a);
         hipLaunchKernelGGL(agents_grad_small_kernel, dim3((17 * H + 9 + 255) / 256, slots), dim3(256), 0, g->stream, a);
         HIP_TRY(hipGetLastError());
         // DDQNAgent.scala:59-61: the target network follows the updated online network
@@ -597,7 +674,7 @@ EPI_API int32_t epi_agents_q_values(epi_agents* g, const int32_t* ids, int32_t c
     a.n_classes = 1;
     a.net_of_class[0] = use_target ? 1 : 0; a.x_of_class[0] = 0;
     // class 0 also writes the hidden activations of row 0 of each slot: scratch no later call relies on
-    hipLaunchKernelGGL(agents_forward_kernel, dim3(1, count), dim3(g->nl.Hp), 0, g->stream, a);
+    hipLaunchKernelGGL(agents_forward_kernel, dim3(1, count), dim3(g->nl.Hp / kTile * 64), tile_lds_bytes(g->nl.Hp), g->stream, a, a.nets);
     HIP_TRY(hipGetLastError());
     std::vector<double> out((size_t)count * kOut);
     for (int k = 0; k < count; ++k)
