@@ -91,7 +91,6 @@ __device__ inline double clip_sym(double v, double c) { return isfinite(c) ? fma
 // does nothing but the ordered multiply-adds; activations sit in LDS as [unit][row], row stride kLS (odd, so the
 // row-major copies to and from global memory are conflict-free too).
 constexpr int kTileRows = 64;
-constexpr int kTile = 16;
 constexpr int kLS = kTileRows + 1;
 
 __host__ __device__ inline size_t tile_lds_bytes(int Hp) { return ((size_t)Hp * kLS + (size_t)kXStride * kTileRows) * sizeof(double); }
@@ -105,6 +104,7 @@ __device__ inline void store_rows(const double* sh, double* dst, int H, int Hp, 
 }
 
 // acc[u] = sum over j < K, in order, of W[j * ldw + u] * act[j * kLS] (first product starts the sum, as .sum does)
+template <int kTile>
 __device__ inline void ordered_tile(const double* __restrict__ W, int ldw, const double* act, int K, double (&acc)[kTile]) {
     double h = act[0];
 #pragma unroll
@@ -120,6 +120,7 @@ __device__ inline void ordered_tile(const double* __restrict__ W, int ldw, const
 // MLP.predict (MLP.scala:15-22) for 64 rows of one class of one slot.  matVec sums left to right.
 // `nets` is the same memory as a.nets, passed as a parameter of its own that nothing is stored through: that lets
 // the compiler prove the weights unclobbered and fetch them with scalar loads.
+template <int kTile>
 __global__ void __launch_bounds__(1024) agents_forward_kernel(AgentsArgs a, const double* __restrict__ nets) {
     extern __shared__ double smem[];
     double* sh_x = smem;                          // [kXStride][64]
@@ -194,6 +195,7 @@ __global__ void __launch_bounds__(1024) agents_forward_kernel(AgentsArgs a, cons
 // ddqnTarget (DDQNAgent.scala:37-47) and the backward pass of MLP.trainBatch (MLP.scala:44-58) for 64
 // samples.  The target equals the prediction in every component but the action taken, so err is zero there
 // and dh2(j) = W3(a)(j) * err(a).  dz = dh * relu(z) -- the activation's value, as the reference has it.
+template <int kTile>
 __global__ void __launch_bounds__(1024) agents_backward_kernel(AgentsArgs a, const double* __restrict__ nets) {
     extern __shared__ double smem[];
     double* sh_err = smem;                        // [64]
@@ -518,8 +520,8 @@ EPI_API epi_agents* epi_agents_create(int32_t n_agents, const epi_learn_hyper* h
         !ok(g->rew.ensure(rows * 8), "rew") || !ok(g->done.ensure(rows * 4), "done") ||
         !ok(g->loss.ensure((size_t)n_agents * 8), "loss") ||
         !ok(hipMemset(g->DZ2.p, 0, rows * Hp * 8), "clear") ||  // columns past H are read by the gradient kernel
-        !ok(hipFuncSetAttribute(reinterpret_cast<const void*>(agents_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(g->nl.Hp)), "lds") ||
-        !ok(hipFuncSetAttribute(reinterpret_cast<const void*>(agents_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(g->nl.Hp)), "lds") ||
+        !ok(hipFuncSetAttribute(reinterpret_cast<const void*>(agents_forward_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(256)), "lds") ||
+        !ok(hipFuncSetAttribute(reinterpret_cast<const void*>(agents_backward_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(256)), "lds") ||
         !ok(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking), "stream") ||
         !ok(hipEventCreate(&g->ev0), "event") || !ok(hipEventCreate(&g->ev1), "event"))
         return nullptr;
@@ -619,10 +621,10 @@ EPI_API int32_t epi_agents_learn(epi_agents* g, const int32_t* ids, int32_t coun
         a.x_of_class[0] = 0; a.x_of_class[1] = 1; a.x_of_class[2] = 1;
         const int Hp = g->nl.Hp, H = g->nl.H;
         if (g->timing) HIP_TRY(hipEventRecord(g->ev0, g->stream));
-        const int tile_threads = Hp / kTile * 64;
         const size_t lds = tile_lds_bytes(Hp);
-        hipLaunchKernelGGL(agents_forward_kernel, dim3(3 * Bp / kTileRows, slots), dim3(tile_threads), lds, g->stream, a, a.nets);
-        hipLaunchKernelGGL(agents_backward_kernel, dim3(Bp / kTileRows, slots), dim3(tile_threads), lds, g->stream, a, a.nets);
+        // 16 hidden units per wave: tiles of 8 (twice the waves) measured slower on the default width
+        hipLaunchKernelGGL(agents_forward_kernel<16>, dim3(3 * Bp / kTileRows, slots), dim3(Hp / 16 * 64), lds, g->stream, a, a.nets);
+        hipLaunchKernelGGL(agents_backward_kernel<16>, dim3(Bp / kTileRows, slots), dim3(Hp / 16 * 64), lds, g->stream, a, a.nets);
         hipLaunchKernelGGL(agents_grad_w2_kernel, dim3((H + kGradRows - 1) / kGradRows, slots), dim3(Hp), 0, g->stream, a);
         hipLaunchKernelGGL(agents_grad_small_kernel, dim3((17 * H + 9 + 255) / 256, slots), dim3(256), 0, g->stream, a);
         HIP_TRY(hipGetLastError());
@@ -674,7 +676,7 @@ EPI_API int32_t epi_agents_q_values(epi_agents* g, const int32_t* ids, int32_t c
     a.n_classes = 1;
     a.net_of_class[0] = use_target ? 1 : 0; a.x_of_class[0] = 0;
     // class 0 also writes the hidden activations of row 0 of each slot: scratch no later call relies on
-    hipLaunchKernelGGL(agents_forward_kernel, dim3(1, count), dim3(g->nl.Hp / kTile * 64), tile_lds_bytes(g->nl.Hp), g->stream, a, a.nets);
+    hipLaunchKernelGGL(agents_forward_kernel<16>, dim3(1, count), dim3(g->nl.Hp / 16 * 64), tile_lds_bytes(g->nl.Hp), g->stream, a, a.nets);
     HIP_TRY(hipGetLastError());
     std::vector<double> out((size_t)count * kOut);
     for (int k = 0; k < count; ++k)

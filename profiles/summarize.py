@@ -32,12 +32,45 @@ def counters(path, kernel_sub):
     return dict(agg), dict(launches)
 
 
+def several_kernels(src, out, bench, names, stats_csv):
+    """A step made of several kernels (the DDQN learn step): per-kernel times and VALU counters, no HBM roofline."""
+    rows = {n: [r for r in csv.DictReader(open(stats_csv)) if n in r["Name"]][0] for n in names}
+    total_ms = sum(float(r["AverageNs"]) for r in rows.values()) / 1e6
+    sq = {n: counters(os.path.join(src, "sq"), n)[0] for n in names}
+    summary = {"workload": bench["config"]["workload"], "bench_line": bench,
+               "rocprof_avg_ms_per_kernel": {n: float(r["AverageNs"]) / 1e6 for n, r in rows.items()},
+               "rocprof_avg_step_ms": total_ms, "bench_avg_launch_ms": bench["roofline"]["avg_launch_ms"],
+               "sq_counters_one_step": sq}
+    with open(out + ".json", "w") as f:
+        json.dump(summary, f, indent=1)
+        f.write("\n")
+    with open(out + ".md", "w") as f:
+        f.write("# rocprofv3 summary: %s\n\n" % summary["workload"])
+        f.write("| quantity | value |\n|---|---|\n")
+        f.write("| bench value | %.4g %s |\n" % (bench["value"], bench["unit"]))
+        f.write("| achieved | %.2f %s = %.3f of %.1f (%s) |\n" % (bench["roofline"]["achieved"], bench["roofline"]["unit"],
+                                                                  bench["roofline"]["frac"], bench["roofline"]["peak"], bench["roofline"]["bound"]))
+        for n, r in rows.items():
+            f.write("| `%s` avg, rocprofv3 --kernel-trace --stats | %.3f ms over %s calls |\n" % (n, float(r["AverageNs"]) / 1e6, r["Calls"]))
+        f.write("| sum of the kernels, rocprofv3 | %.3f ms |\n" % total_ms)
+        f.write("| device time of one learn call, HIP events in bench.py | %.3f ms |\n" % summary["bench_avg_launch_ms"])
+        for n in names:
+            for k in sorted(sq[n]):
+                f.write("| %s: %s | %.4g |\n" % (n, k, sq[n][k]))
+        if "cpu_baseline" in bench:
+            f.write("| cpu_baseline | %.4g %s on %d threads (%s) |\n" % (bench["cpu_baseline"]["value"], bench["cpu_baseline"]["unit"],
+                                                                        bench["cpu_baseline"]["cores"], bench["cpu_baseline"]["sample"]))
+    print("wrote", out + ".json", out + ".md")
+
+
 def main():
     src, out = sys.argv[1], sys.argv[2]
     bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
     kernel_sub = bench["roofline"]["kernel"]
     stats_csv = newest(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")))[0]
     shutil.copy(stats_csv, out + "_kernel_stats.csv")
+    if " + " in kernel_sub:
+        return several_kernels(src, out, bench, kernel_sub.split(" + "), stats_csv)
     kstats = [r for r in csv.DictReader(open(stats_csv)) if kernel_sub in r["Name"]][0]
     c = {}
     launches = 0
