@@ -268,6 +268,157 @@ private:
     size_t pos_ = 0;
 };
 
+// ---- ReplayBuffer.scala / DDQNAgent.scala / MLP.scala: learners held by the engine -----------------------
+struct Transition {  // ReplayBuffer.scala:8
+    State s;
+    int a;
+    double r;
+    State s2;
+    bool done;
+};
+
+// java.util.Random (48-bit LCG of the JDK javadoc) for the agent's own epsilon-greedy draws (DDQNAgent.scala:14,28).
+class JavaRandom {
+public:
+    explicit JavaRandom(int64_t seed) : state_((uint64_t)(seed ^ 0x5DEECE66DLL) & kMask) {}
+    int32_t next(int bits) {
+        state_ = (state_ * 0x5DEECE66DULL + 0xBULL) & kMask;
+        return (int32_t)(int64_t)(state_ >> (48 - bits));
+    }
+    int32_t nextInt(int32_t bound) {
+        int32_t r = next(31);
+        const int32_t m = bound - 1;
+        if ((bound & m) == 0) return (int32_t)(((int64_t)bound * (int64_t)r) >> 31);
+        for (int32_t u = r;; u = next(31)) {
+            r = u % bound;
+            if ((int32_t)((uint32_t)u - (uint32_t)r + (uint32_t)m) >= 0) return r;
+        }
+    }
+    double nextDouble() {
+        const int64_t hi = (int64_t)next(26) << 27;
+        return (double)(hi + next(27)) * (1.0 / (double)(1LL << 53));
+    }
+
+private:
+    static constexpr uint64_t kMask = (1ULL << 48) - 1;
+    uint64_t state_;
+};
+
+// The agents of one world in one engine handle (epi_agents_*): replay buffers, online and target networks.
+class Agents {
+public:
+    explicit Agents(const std::vector<HyperParams>& hps, int maxGradAccum = 4, int device = 0) : hps_(hps) {
+        std::vector<epi_learn_hyper> raw;
+        for (auto& h : hps)
+            raw.push_back(epi_learn_hyper{h.gamma, h.lr, h.clipQ, h.gradClip, h.emaAlpha, h.hidden, h.replayCapacity,
+                                          h.targetUpdateEvery, h.batchSize * std::max(1, maxGradAccum)});
+        h_ = epi_agents_create((int32_t)raw.size(), raw.data(), device);
+        if (!h_) {
+            char buf[1024];
+            epi_last_error(buf, sizeof buf);
+            throw std::runtime_error(buf);
+        }
+    }
+    ~Agents() { epi_agents_destroy(h_); }
+    Agents(const Agents&) = delete;
+    Agents& operator=(const Agents&) = delete;
+
+    int size() const { return (int)hps_.size(); }
+    void observe(const std::vector<int32_t>& ids, const std::vector<Transition>& trs) {  // DDQNAgent.scala:34
+        std::vector<epi_state> s, s2;
+        std::vector<int32_t> a;
+        std::vector<double> r;
+        std::vector<uint8_t> d;
+        for (auto& t : trs) { s.push_back(t.s.c()); s2.push_back(t.s2.c()); a.push_back(t.a); r.push_back(t.r); d.push_back(t.done ? 1 : 0); }
+        check(epi_agents_observe(h_, ids.data(), (int32_t)trs.size(), s.data(), a.data(), r.data(), s2.data(), d.data()));
+    }
+    std::vector<int32_t> replaySize() {  // :69
+        std::vector<int32_t> out(hps_.size());
+        check(epi_agents_replay_size(h_, out.data()));
+        return out;
+    }
+    std::vector<int32_t> sample(int agent, int n) {  // ReplayBuffer.scala:21-22, buffer positions
+        std::vector<int32_t> out((size_t)std::max(n, 1));
+        int32_t taken = 0;
+        check(epi_agents_sample(h_, agent, n, out.data(), &taken));
+        out.resize((size_t)taken);
+        return out;
+    }
+    // DDQNAgent.learn (:51-65) for the listed agents in one call; returns the losses, fills ema if given
+    std::vector<double> learn(const std::vector<int32_t>& ids, const std::vector<int32_t>& batch, const std::vector<int32_t>& gradAccum,
+                              const std::vector<int64_t>& steps, std::vector<double>* ema = nullptr) {
+        std::vector<double> loss(ids.size()), e(ids.size());
+        check(epi_agents_learn(h_, ids.data(), (int32_t)ids.size(), batch.data(), gradAccum.data(), steps.data(), loss.data(), e.data()));
+        if (ema) *ema = e;
+        return loss;
+    }
+    std::vector<int32_t> greedy(const std::vector<int32_t>& ids, const std::vector<State>& states, std::vector<double>* q = nullptr) {
+        std::vector<epi_state> raw;
+        for (auto& s : states) raw.push_back(s.c());
+        std::vector<int32_t> g(ids.size());
+        if (q) q->assign(ids.size() * 8, 0.0);
+        check(epi_agents_q_values(h_, ids.data(), (int32_t)ids.size(), raw.data(), 0, q ? q->data() : nullptr, g.data()));
+        return g;
+    }
+    // [W1, b1, W2, b2, W3, b3] of one agent's online (or target) network
+    std::vector<std::vector<double>> weights(int agent, bool target = false) {
+        const size_t h = (size_t)hps_[agent].hidden;
+        std::vector<std::vector<double>> W{std::vector<double>(h * 7), std::vector<double>(h), std::vector<double>(h * h),
+                                           std::vector<double>(h), std::vector<double>(8 * h), std::vector<double>(8)};
+        check(epi_agents_get_weights(h_, agent, target ? 1 : 0, W[0].data(), W[1].data(), W[2].data(), W[3].data(), W[4].data(), W[5].data()));
+        return W;
+    }
+    const HyperParams& hp(int agent) const { return hps_[agent]; }
+
+private:
+    std::vector<HyperParams> hps_;
+    epi_agents* h_ = nullptr;
+};
+
+// DDQNAgent.scala:6-70: the epsilon stream on the host, the networks in the shared handle.
+class DDQNAgent {
+public:
+    DDQNAgent(std::shared_ptr<Agents> pool, int index) : pool_(std::move(pool)), k_(index), hp_(pool_->hp(index)) {}
+    double epsilonNow() const {  // :16-19,67
+        const double frac = std::min(1.0, (double)steps / (double)std::max(1, hp_.epsilonDecaySteps));
+        return hp_.epsilonStart + (hp_.epsilonEnd - hp_.epsilonStart) * frac;
+    }
+    int actGreedy(const State& s) { return pool_->greedy({k_}, {s})[0]; }  // :22-23
+    // the random branch of actWithEpsilon (:26-30) without the network: 0..7, or -1 where argmax Q is taken
+    int explores(double eps, bool countStep) {
+        if (countStep) steps += 1;
+        return rnd_.nextDouble() < eps ? rnd_.nextInt(8) : -1;
+    }
+    int actWithEpsilon(const State& s, double eps, bool countStep = false) {
+        const int a = explores(eps, countStep);
+        return a >= 0 ? a : actGreedy(s);
+    }
+    int act(const State& s) { return actWithEpsilon(s, epsilonNow(), true); }  // :32: epsilon is read before the step counts
+    void observe(const Transition& tr) { pool_->observe({k_}, {tr}); }          // :34
+    double learn(int batch, int gradAccumSteps = 4) {                             // :51-65
+        std::vector<double> ema;
+        const double loss = pool_->learn({k_}, {batch}, {gradAccumSteps}, {steps}, &ema)[0];
+        emaLoss_ = ema[0];
+        return loss;
+    }
+    double emaLossNow() const { return emaLoss_; }
+    int replaySize() { return pool_->replaySize()[(size_t)k_]; }
+    std::vector<double> qValues(const State& s) {  // :70
+        std::vector<double> q;
+        pool_->greedy({k_}, {s}, &q);
+        return q;
+    }
+    int64_t steps = 0;
+    void setEma(double e) { emaLoss_ = e; }
+
+private:
+    std::shared_ptr<Agents> pool_;
+    int32_t k_;
+    HyperParams hp_;
+    JavaRandom rnd_{9};
+    double emaLoss_ = 0.0;
+};
+
 // ---- WorldToy.scala -------------------------------------------------------------------------------
 class WorldToy {
 public:
@@ -281,14 +432,17 @@ public:
         int lastA = 0;
         int arrival = -1;     // first step index with I >= 10 since the last reset (Validation.arrivalTime); -1 = not yet
         double peakI = 0.0;   // running Validation.peakI
+        std::shared_ptr<DDQNAgent> agent;  // WorldToy.scala:50, present once the world learns
+        int64_t lastLearnStep = 0;
     };
     using Step = std::vector<std::tuple<std::string, State, double>>;
 
     WorldToy(const HyperParams& hp, const State& base, int seedIdx = 0, const Matrix& conn = ToyConn::W(),
              std::function<std::shared_ptr<EpidemicEnv>()> makeEnv = [] { return std::make_shared<EpidemicEnv>(); },
              std::function<std::shared_ptr<EpidemicEnv>(const std::string&, int)> makeEnvFor = nullptr, bool validate = false,
-             const std::vector<Geo::Country>& countries = ToyConn::C())
-        : hp_(hp), base_(base) {
+             const std::vector<Geo::Country>& countries = ToyConn::C(),
+             const std::map<std::string, HyperParams>& countryHyperParams = {}, bool learning = true)
+        : hp_(hp), base_(base), learning_(learning) {
         const int n = (int)countries.size();
         std::vector<int32_t> pops, seeds;
         std::vector<epi_env_params> envs;
@@ -299,7 +453,8 @@ public:
             seeds.push_back(env->seed());
             envs.push_back(env->raw());
             profs.push_back(env->countryProfile().c());
-            nodes.push_back(Node{i, countries[i].name, countries[i].pop, env, hp, State{}});
+            const auto chp = countryHyperParams.find(countries[i].name);
+            nodes.push_back(Node{i, countries[i].name, countries[i].pop, env, chp == countryHyperParams.end() ? hp : chp->second, State{}});
         }
         const std::vector<double> flat = flatten(conn);
         epi_world_desc d{};
@@ -341,10 +496,16 @@ public:
         for (auto& nd : nodes) { nd.arrival = -1; nd.peakI = 0.0; }
     }
 
-    // WorldToy.stepOne (:83-170) with never-trained agents: epsilon-greedy draws follow the JVM streams;
-    // the DDQN update itself stays with the trainer.
+    // losses of the last stepOne: what agent.learn returned, or -1 where the node did not learn
+    std::vector<double> lastLosses;
+    std::shared_ptr<Agents> agents() { return pool_; }
+
+    // WorldToy.stepOne (:83-170).  With `learning` every node acts through its own DDQNAgent, observes its transition
+    // and learns on its own schedule (:147-167); without it the agents stay untrained and only their
+    // epsilon-greedy streams are followed.
     Step stepOne(int tMax) {
         const int n = (int)nodes.size();
+        if (learning_) return stepOneLearning(tMax);
         if (streams_.empty()) streams_.resize(n);
         std::vector<int32_t> acts(n);
         bool needGreedy = false;
@@ -375,8 +536,18 @@ public:
     }
 
     Step stepOneGreedy(int tMax) {  // :172-235
-        ensureMlp();
         const int n = (int)nodes.size();
+        if (learning_ && pool_) {  // every node asks its own, possibly trained, network (:177)
+            std::vector<int32_t> ids(n);
+            std::vector<State> ss;
+            for (int c = 0; c < n; ++c) { ids[c] = c; ss.push_back(nodes[c].s); }
+            std::vector<int32_t> acts = pool_->greedy(ids, ss);
+            std::vector<epi_state> out(n);
+            std::vector<double> rew(n);
+            check(epi_world_step(h_, acts.data(), nullptr, tMax, out.data(), rew.data()));
+            return collect(out, rew, acts);
+        }
+        ensureMlp();
         std::vector<epi_state> out(n);
         std::vector<double> rew(n);
         std::vector<int32_t> acts(n);
@@ -395,6 +566,68 @@ private:
         std::vector<int32_t> buf;
         size_t pos = 0;
     };
+    static int learningIntensity(const std::string& name) { return name == "India" ? 2 : 1; }  // WorldToy.scala:157-162
+    Step stepOneLearning(int tMax) {
+        const int n = (int)nodes.size();
+        if (!pool_) {
+            std::vector<HyperParams> hps;
+            for (auto& nd : nodes) hps.push_back(nd.hyperParams);
+            pool_ = std::make_shared<Agents>(hps, 4);
+            for (auto& nd : nodes) nd.agent = std::make_shared<DDQNAgent>(pool_, nd.idx);
+        }
+        std::vector<State> before;
+        std::vector<int32_t> acts(n), gids;
+        std::vector<State> gstates;
+        for (int c = 0; c < n; ++c) {
+            before.push_back(nodes[c].s);
+            acts[c] = nodes[c].agent->explores(nodes[c].agent->epsilonNow(), true);  // :88
+            if (acts[c] < 0) { gids.push_back(c); gstates.push_back(nodes[c].s); }
+        }
+        if (!gids.empty()) {
+            const std::vector<int32_t> g = pool_->greedy(gids, gstates);
+            for (size_t k = 0; k < gids.size(); ++k) acts[gids[k]] = g[k];
+        }
+        std::vector<epi_state> out(n);
+        std::vector<double> rew(n);
+        check(epi_world_step(h_, acts.data(), nullptr, tMax, out.data(), rew.data()));
+        const auto flows = lastFlows();
+        std::vector<int32_t> ids(n);
+        std::vector<Transition> trs;
+        for (int c = 0; c < n; ++c) {
+            // the post-env.step state the transition holds (:90,99): the returned state without the mobility flows
+            // of :132-136 and with env.step's own clock
+            State s2 = State::from(out[c]);
+            s2.s -= (double)flows.first[c];
+            s2.i -= (double)flows.second[c];
+            s2.t = before[c].t + 1;
+            const double nn = std::max(1.0, s2.s + s2.i + s2.r + s2.d);
+            const bool done = s2.t >= s2.tMax || s2.i / nn < 1e-5 || s2.d / nn > 0.02;  // env.scala:137
+            ids[c] = c;
+            trs.push_back(Transition{before[c], acts[c], rew[c], s2, done});
+        }
+        pool_->observe(ids, trs);
+        Step res = collect(out, rew, acts);
+        ++gStep_;
+        const std::vector<int32_t> sizes = pool_->replaySize();
+        std::vector<int32_t> due, batch, accum;
+        std::vector<int64_t> steps;
+        for (auto& nd : nodes)
+            if (gStep_ - nd.lastLearnStep >= nd.hyperParams.learnEvery && sizes[nd.idx] >= nd.hyperParams.batchSize * 4) {
+                due.push_back(nd.idx); batch.push_back(nd.hyperParams.batchSize); accum.push_back(learningIntensity(nd.name));
+                steps.push_back(nd.agent->steps);
+            }
+        lastLosses.assign((size_t)n, -1.0);
+        if (!due.empty()) {
+            std::vector<double> ema;
+            const std::vector<double> loss = pool_->learn(due, batch, accum, steps, &ema);
+            for (size_t k = 0; k < due.size(); ++k) {
+                nodes[due[k]].lastLearnStep = gStep_;
+                nodes[due[k]].agent->setEma(ema[k]);
+                lastLosses[due[k]] = loss[k];
+            }
+        }
+        return res;
+    }
     void syncNodes() {
         auto ss = snapshotStates();
         for (size_t c = 0; c < nodes.size(); ++c) nodes[c].s = ss[c];
@@ -423,6 +656,9 @@ private:
     State base_;
     epi_world* h_ = nullptr;
     int stepsDone_ = 0;
+    bool learning_ = true;
+    int64_t gStep_ = 0;
+    std::shared_ptr<Agents> pool_;
     std::vector<Stream> streams_;
     std::vector<double> W1_, W2_, W3_;
 };

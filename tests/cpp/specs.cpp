@@ -193,6 +193,52 @@ static void wireFormats() {
     EXPECT(w.nodes[0].arrival == -1 && w.nodes[0].peakI == 0.0);
 }
 
+// ReplayBufferSpec.scala:13-35 against the engine's replay buffers, then a world whose agents learn.
+static void replayBufferSpec() {
+    auto mkState = [](int i) { return State{1000.0 - i, (double)i, 0.0, 0.0, 0.0, 100.0, i, 999, 1}; };
+    auto tr = [&](int i) { return Transition{mkState(i), i % 3, (double)i, mkState(i + 1), false}; };
+    HyperParams hp;
+    hp.hidden = 16; hp.replayCapacity = 16; hp.batchSize = 4;
+    Agents ab({hp, hp}, 3);
+    for (int i = 0; i < 16; ++i) ab.observe({0, 1}, {tr(i), tr(i)});
+    const auto sa = ab.sample(0, 12), sb = ab.sample(1, 12);
+    EXPECT(sa.size() == 12 && sa == sb);  // same Random(123), same contents
+    HyperParams small = hp;
+    small.replayCapacity = 4; small.batchSize = 1;
+    Agents rb({small}, 4);
+    for (int i = 0; i < 8; ++i) rb.observe({0}, {tr(i)});
+    EXPECT(rb.replaySize()[0] == 4);
+    auto got = rb.sample(0, 4);
+    std::sort(got.begin(), got.end());
+    EXPECT((got == std::vector<int32_t>{0, 1, 2, 3}));  // the four ring slots, holding transitions 4..7
+
+    // two identical learning worlds stay identical, learn on schedule, and their networks move
+    auto makeWorld = [] {
+        HyperParams h;
+        h.hidden = 32; h.batchSize = 4; h.learnEvery = 3; h.epsilonDecaySteps = 40; h.targetUpdateEvery = 7; h.replayCapacity = 30;
+        std::map<std::string, HyperParams> chp;
+        HyperParams india = h;
+        india.batchSize = 3; india.learnEvery = 2; india.lr = 5e-3;
+        chp["India"] = india;
+        return std::make_unique<WorldToy>(h, State{1e6, 0, 0, 0, 0, 10000, 0, 400, 1}, 0, ToyConn::W(),
+                                          [] { return std::make_shared<EpidemicEnv>(); }, nullptr, true, ToyConn::C(), chp, true);
+    };
+    auto w1 = makeWorld(), w2 = makeWorld();
+    int learned = 0, firstLearn = -1;
+    for (int k = 0; k < 60; ++k) {
+        const auto a = w1->stepOne(400), b = w2->stepOne(400);
+        EXPECT(a == b && w1->lastLosses == w2->lastLosses);
+        for (double l : w1->lastLosses)
+            if (l >= 0) { ++learned; if (firstLearn < 0) firstLearn = k; }
+    }
+    // India (batch 3) holds 12 transitions after 12 steps and learns every 2nd step from then on; the others (batch 4)
+    // need 16 transitions
+    EXPECT(firstLearn == 11 && learned > 60);
+    const auto fresh = Agents({w1->nodes[0].hyperParams}, 4).weights(0);
+    EXPECT(w1->agents()->weights(0) == w2->agents()->weights(0) && w1->agents()->weights(0) != fresh);
+    EXPECT(w1->nodes[0].agent->replaySize() == 30 && w1->nodes[0].agent->steps == 60);
+}
+
 int main() {
     if (epi_device_count() < 1) {
         std::printf("no HIP device: the specs need the GPU engine\n");
@@ -202,7 +248,7 @@ int main() {
         const char* name;
         void (*fn)();
     } specs[] = {{"ValidationSpec", validationSpec}, {"MobilitySpec", mobilitySpec}, {"CalibrationSpec", calibrationSpec},
-                 {"EvalDeterminismSpec", evalDeterminismSpec}, {"HeterogeneitySpec", heterogeneitySpec}, {"WireFormats", wireFormats}};
+                 {"EvalDeterminismSpec", evalDeterminismSpec}, {"HeterogeneitySpec", heterogeneitySpec}, {"WireFormats", wireFormats}, {"ReplayBufferSpec", replayBufferSpec}};
     for (auto& s : specs) {
         const int before = failures;
         try {
