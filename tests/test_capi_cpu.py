@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(epi):
 def test_struct_layouts_match_header(epi):
     from epidemicsimulator_amd import _capi
     assert C.sizeof(_capi.CState) == 64 and C.sizeof(_capi.Profile) == 72 and C.sizeof(_capi.EnvParams) == 48
-    assert C.sizeof(_capi.CHyper) == 48
+    assert C.sizeof(_capi.CHyper) == 48 and C.sizeof(_capi.LearnHyper) == 56 == C.sizeof(O.LearnHyper)
     assert C.sizeof(O.State) == C.sizeof(_capi.CState)
 
 
@@ -132,10 +132,20 @@ def test_compute_entry_points_need_a_gpu(epi):
     assert "HIP" in str(ei.value)
     with pytest.raises(epi.EpiError):
         epi.WorldToy(epi.HyperParams(), synth.base_state(3))
+    with pytest.raises(epi.EpiError) as ei:
+        epi.Agents([epi.HyperParams()])
+    assert "HIP" in str(ei.value)
 
 
 def test_bad_arguments_are_rejected_before_the_device(epi):
     from epidemicsimulator_amd import synth
+    with pytest.raises(epi.EpiError) as ei:                # one hidden width per handle, checked before any device call
+        epi.Agents([epi.HyperParams(hidden=32), epi.HyperParams(hidden=64)])
+    assert "hidden" in str(ei.value)
+    with pytest.raises(epi.EpiError):
+        epi.Agents([epi.HyperParams(hidden=512)])
+    with pytest.raises(epi.EpiError):
+        epi.Agents([epi.HyperParams(replay_capacity=0)])
     wl = synth.small_workload(8, 1, 1, 3)
     with pytest.raises(epi.IllegalArgumentException):      # Validation.assertState on the initial states
         epi.GridEngine(epi.HyperParams(), 3, synth.base_state(3).copy(r=2.0), 0, [c.pop for c in wl["countries"]], wl["conn"],
