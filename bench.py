@@ -8,7 +8,7 @@ point is one episode of T world steps over n countries, so a step processes G*n*
 Inputs (graph, tables, targets) are resident in HBM before the timed region starts.
 
 With N > 1 (launched by torch.distributed.run, one rank per GPU) the flat grid is cut into N
-contiguous slabs, one per rank; after its slab every rank takes part in one RCCL all-gather of the
+interleaved shares (rank r runs points r, r + N, ...); after its share every rank takes part in one RCCL all-gather of the
 fp64 loss surface and then finds the first minimum.  Total work is fixed: "scaling": "strong".
 
 Rank 0 prints one JSON line.  `roofline` prices the episode kernel by its ALGORITHMIC bytes
@@ -315,15 +315,16 @@ def main():
                        wl["profiles"], wl["betas"], wl["travel"], wl["t_arrive"], wl["t_peak"], True, device=local_rank)
 
     # contiguous beta-major slabs, padded so that the all-gather pieces have equal size
-    from epidemicsimulator_amd.dist import gather_surface, slab_bounds
-    g0, cnt, per = slab_bounds(G, world, rank)
+    # interleaved split: rank r runs grid points r, r + world, ...; shares padded so that the all-gather pieces have equal size
+    from epidemicsimulator_amd.dist import gather_surface_strided, strided_bounds
+    g0, gstride, cnt, per = strided_bounds(G, world, rank)
     loss_local = torch.zeros(per, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def one_step():
         if cnt > 0:
-            eng.enqueue(g0, cnt, loss_local.data_ptr(), stream)
-        host = gather_surface(loss_local, G, world, force=use_dist)  # 8*G bytes back to the host
+            eng.enqueue(g0, cnt, loss_local.data_ptr(), stream, g_stride=gstride)
+        host = gather_surface_strided(loss_local, G, world, force=use_dist)  # 8*G bytes back to the host
         return E.grid_argmin(host)                   # Calibrate.scala:112's strict '<' scan
 
     def fence():
@@ -365,7 +366,7 @@ def main():
         "config": {"workload": "%s: %d countries, %dx%d beta x travel grid, %d-step episodes, %s" % (
             wl["name"], n, nb, nt, T, "CSR graph" if isinstance(wl["conn"], tuple) else "dense graph"),
             "grid_points": G, "country_steps_per_step": G * n * T,
-            "parallelism": "grid slabs of %d points per GPU + RCCL all-gather of the fp64 loss surface" % per if world > 1
+            "parallelism": "interleaved shares of %d grid points per GPU + RCCL all-gather of the fp64 loss surface" % per if world > 1
             else "single GPU", "best_idx": int(best[0]), "best_loss": float(best[1])},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

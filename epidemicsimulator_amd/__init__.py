@@ -931,11 +931,20 @@ class GridEngine:
                                  pk.ctypes.data if want_metrics else None, 0, None))
         return dict(loss=loss, arrival=arr, peak=pk)
 
+    def run_strided(self, g_begin: int, g_stride: int, g_count: int, want_metrics: bool = True):
+        """Synchronous run of grid points g_begin + k * g_stride, k < g_count (an interleaved share of the grid)."""
+        loss = np.zeros(g_count)
+        arr = np.zeros((g_count, self.n), dtype=np.int32) if want_metrics else None
+        pk = np.zeros((g_count, self.n)) if want_metrics else None
+        check(lib().epi_grid_run_strided(self._h, g_begin, g_stride, g_count, loss.ctypes.data,
+                                         arr.ctypes.data if want_metrics else None, pk.ctypes.data if want_metrics else None, 0, None))
+        return dict(loss=loss, arrival=arr, peak=pk)
+
     def enqueue(self, g_begin: int, g_count: int, loss_dev_ptr: int, stream: int = 0, arrival_dev_ptr: int = 0,
-                peak_dev_ptr: int = 0):
+                peak_dev_ptr: int = 0, g_stride: int = 1):
         """Asynchronous run into device buffers (raw addresses) on `stream` (a hipStream_t address)."""
-        check(lib().epi_grid_run(self._h, g_begin, g_count, loss_dev_ptr or None, arrival_dev_ptr or None,
-                                 peak_dev_ptr or None, 1, stream or None))
+        check(lib().epi_grid_run_strided(self._h, g_begin, g_stride, g_count, loss_dev_ptr or None, arrival_dev_ptr or None,
+                                         peak_dev_ptr or None, 1, stream or None))
 
     def status(self):
         check(lib().epi_grid_status(self._h))

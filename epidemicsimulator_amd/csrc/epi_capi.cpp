@@ -396,12 +396,12 @@ const char* status_text(int code) {
 }
 
 // First failing episode of a run, from the device error table.
-int32_t collect_errors(const DevBuf& err, int count, int g_begin) {
+int32_t collect_errors(const DevBuf& err, int count, int g_begin, int g_stride = 1) {
     std::vector<int32_t> h((size_t)count * 4);
     HIP_TRY(hipMemcpy(h.data(), err.p, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (int e = 0; e < count; ++e)
         if (h[(size_t)e * 4] != 0)
-            return fail(h[(size_t)e * 4], "%s (instance %d, country %d, t=%d)", status_text(h[(size_t)e * 4]), g_begin + e,
+            return fail(h[(size_t)e * 4], "%s (instance %d, country %d, t=%d)", status_text(h[(size_t)e * 4]), g_begin + e * g_stride,
                         h[(size_t)e * 4 + 1], h[(size_t)e * 4 + 2]);
     return EPI_OK;
 }
@@ -439,7 +439,7 @@ struct epi_grid {
     std::vector<int> greedy_steps;
     EpisodeBuffers work;
     DevBuf loss_tmp, arrival_tmp, peak_tmp;
-    int last_count = 0, last_g_begin = 0;
+    int last_count = 0, last_g_begin = 0, last_g_stride = 1;
     bool pending = false;
     // optional timing of the episode kernel launches (HIP events on the launch stream)
     bool timing = false;
@@ -905,14 +905,20 @@ EPI_API int32_t epi_grid_status(epi_grid* g) {
     HIP_TRY(hipDeviceSynchronize());
     if (!g->pending) return EPI_OK;
     g->pending = false;
-    return collect_errors(g->work.err, g->last_count, g->last_g_begin);
+    return collect_errors(g->work.err, g->last_count, g->last_g_begin, g->last_g_stride);
 }
 
 EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, double* loss, int32_t* arrival, double* peak,
                              int32_t out_on_device, void* stream) {
+    return epi_grid_run_strided(g, g_begin, 1, g_count, loss, arrival, peak, out_on_device, stream);
+}
+
+EPI_API int32_t epi_grid_run_strided(epi_grid* g, int32_t g_begin, int32_t g_stride, int32_t g_count, double* loss,
+                                     int32_t* arrival, double* peak, int32_t out_on_device, void* stream) {
     if (!g) return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_run: null handle");
     const int G = g->n_beta * g->n_travel;
-    if (g_begin < 0 || g_count < 0 || g_begin + g_count > G) return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_run: slab [%d,%d) outside the %d grid points", g_begin, g_begin + g_count, G);
+    if (g_begin < 0 || g_count < 0 || g_stride < 1 || (g_count > 0 && (int64_t)g_begin + (int64_t)(g_count - 1) * g_stride >= G))
+        return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_run: points %d + k*%d, k < %d, leave the %d grid points", g_begin, g_stride, g_count, G);
     if (g_count == 0) return EPI_OK;
     HIP_TRY(hipSetDevice(g->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -941,7 +947,7 @@ EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, doub
 
     EpisodeArgs ea{};
     ea.n = n; ea.npad = npad; ea.count = g_count;
-    ea.seed_idx = g->seed_idx; ea.n_travel = g->n_travel; ea.g_begin = g_begin;
+    ea.seed_idx = g->seed_idx; ea.n_travel = g->n_travel; ea.g_begin = g_begin; ea.g_stride = g_stride;
     ea.step_t_max = g->steps;  // world.stepOne(cfg.stepsPerEpoch), Calibrate.scala:70
     ea.validate = 1;
     g->graph.fill(ea);
@@ -1002,6 +1008,7 @@ EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, doub
     g->pending = true;
     g->last_count = g_count;
     g->last_g_begin = g_begin;
+    g->last_g_stride = g_stride;
     if (out_on_device) return EPI_OK;
 
     HIP_TRY(hipStreamSynchronize(s));
@@ -1264,7 +1271,7 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
     }
     EpisodeArgs ea{};
     ea.n = n; ea.npad = npad; ea.count = B;
-    ea.seed_idx = w->seed_idx; ea.n_travel = 0; ea.g_begin = 0;
+    ea.seed_idx = w->seed_idx; ea.n_travel = 0; ea.g_begin = 0; ea.g_stride = 1;
     ea.t_begin = 0; ea.t_end = 1;
     ea.step_t_max = t_max;
     ea.validate = w->validate;

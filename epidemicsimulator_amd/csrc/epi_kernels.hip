@@ -59,7 +59,7 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int e = blockIdx.x;
-    const int g = a.g_begin + e;
+    const int g = a.g_begin + e * a.g_stride;
     const int n = a.n;
     const int ti = a.n_travel > 0 ? g % a.n_travel : 0;
     int bi = a.n_travel > 0 ? g / a.n_travel : g;
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int e = blockIdx.x;
-    const int g = a.g_begin + e;
+    const int g = a.g_begin + e * a.g_stride;
     const int ti = a.n_travel > 0 ? g % a.n_travel : 0;
     int bi = a.n_travel > 0 ? g / a.n_travel : g;
     bi = bi < a.beta_rows ? bi : a.beta_rows - 1;
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(64) void episode_tiny_kernel(const EpisodeArgs a) {
     const bool live = e < a.count;
     const bool real = live && c < n;
     const int NP = a.npad;  // 64
-    const int g = a.g_begin + (live ? e : 0);
+    const int g = a.g_begin + (live ? e : 0) * a.g_stride;
     const int ti = a.n_travel > 0 ? g % a.n_travel : 0;
     int bi = a.n_travel > 0 ? g / a.n_travel : g;
     bi = bi < a.beta_rows ? bi : a.beta_rows - 1;

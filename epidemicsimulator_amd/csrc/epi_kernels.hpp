@@ -30,8 +30,8 @@ struct EllBlock {
 
 struct EpisodeArgs {
     int n, npad, count;
-    int seed_idx, n_travel;  // travel variant of the seed row: (g_begin + e) % n_travel; < 0 = none
-    int g_begin;             // flat grid index of episode 0 (beta index = g / n_travel)
+    int seed_idx, n_travel;  // travel variant of the seed row: g % n_travel for grid point g; < 0 = none
+    int g_begin, g_stride;   // episode e runs flat grid point g = g_begin + e * g_stride (beta index = g / n_travel)
     int t_begin, t_end;
     int step_t_max;          // the tMax argument of stepOne (WorldToy.scala:135)
     int validate;

@@ -151,6 +151,11 @@ epi_grid *epi_grid_create(const epi_grid_desc *desc);
  * collected by epi_grid_status().  Otherwise they are host memory and the call is synchronous. */
 int32_t epi_grid_run(epi_grid *g, int32_t g_begin, int32_t g_count, double *loss, int32_t *arrival, double *peak,
                      int32_t out_on_device, void *stream);
+/* The same for the grid points g_begin + k * g_stride, k < g_count (outputs indexed by k).  An interleaved split
+ * over ranks (g_begin = rank, g_stride = ranks) balances the sweep better than contiguous slabs: episodes of one
+ * beta row cost about the same, episodes of different rows do not. */
+int32_t epi_grid_run_strided(epi_grid *g, int32_t g_begin, int32_t g_stride, int32_t g_count, double *loss,
+                             int32_t *arrival, double *peak, int32_t out_on_device, void *stream);
 /* Waits for the last enqueued run and returns its status (first failing grid point wins). */
 int32_t epi_grid_status(epi_grid *g);
 int32_t epi_grid_destroy(epi_grid *g);

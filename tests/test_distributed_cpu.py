@@ -19,31 +19,37 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, grid_points, surface, out_dir):
+def _worker(rank, world, port, grid_points, surface, out_dir, strided=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
-    from epidemicsimulator_amd.dist import first_min, gather_surface, slab_bounds
+    from epidemicsimulator_amd.dist import first_min, gather_surface, gather_surface_strided, slab_bounds, strided_bounds
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    g0, cnt, per = slab_bounds(grid_points, world, rank)
-    local = torch.zeros(per, dtype=torch.float64)
-    local[:cnt] = torch.from_numpy(surface[g0:g0 + cnt])  # this rank's slab of the loss surface
-    full = gather_surface(local, grid_points, world)
+    if strided:   # the split bench.py uses: rank r holds grid points r, r + world, ...
+        g0, stride, cnt, per = strided_bounds(grid_points, world, rank)
+        local = torch.full((per,), -1.0, dtype=torch.float64)
+        local[:cnt] = torch.from_numpy(surface[g0::stride].copy())
+        full = gather_surface_strided(local, grid_points, world)
+    else:
+        g0, cnt, per = slab_bounds(grid_points, world, rank)
+        local = torch.zeros(per, dtype=torch.float64)
+        local[:cnt] = torch.from_numpy(surface[g0:g0 + cnt])  # this rank's slab of the loss surface
+        full = gather_surface(local, grid_points, world)
     idx, best = first_min(full)
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.concatenate([full, [idx, best]]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("grid_points", [12, 7, 1])
-def test_two_rank_gather_and_argmin(tmp_path, grid_points):
+@pytest.mark.parametrize("grid_points,strided", [(12, False), (7, False), (1, False), (12, True), (7, True), (1, True)])
+def test_two_rank_gather_and_argmin(tmp_path, grid_points, strided):
     import torch.multiprocessing as mp
     rng = np.random.default_rng(grid_points)
     surface = np.round(rng.random(grid_points) * 10, 1)  # coarse values: repeated minima exercise "first"
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, grid_points, surface, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, grid_points, surface, str(tmp_path), strided), nprocs=2, join=True)
     want_idx = int(np.argmin(surface))
     for rank in range(2):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % rank))
@@ -65,6 +71,20 @@ def test_slab_bounds_cover_the_grid():
                 assert cnt <= per
             assert seen == list(range(G)) and len(pers) == 1
     assert slab_bounds(4096, 8, 3) == (1536, 512, 512)
+
+
+def test_strided_bounds_cover_the_grid():
+    sys.path.insert(0, ROOT)
+    from epidemicsimulator_amd.dist import strided_bounds
+    for G in (0, 1, 7, 20, 1024, 4096, 4097):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                g0, stride, cnt, per = strided_bounds(G, world, r)
+                assert stride == world and cnt <= per == (G + world - 1) // world
+                seen += [g0 + k * stride for k in range(cnt)]
+            assert sorted(seen) == list(range(G))
+    assert strided_bounds(4096, 8, 3) == (3, 8, 512, 512)
 
 
 def test_oracle_surface_through_the_exchange(tmp_path, oracle):

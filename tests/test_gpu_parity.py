@@ -288,6 +288,30 @@ def test_grid_slabs_equal_whole(epi):
     eng.close()
 
 
+def test_grid_strided_shares_equal_whole(epi):
+    """The interleaved split of the multi-GPU sweep: rank r's points r, r + ranks, ... give the same losses and
+    metrics as the same points of one whole run, for a rank count that does not divide the grid."""
+    from epidemicsimulator_amd import synth
+    from epidemicsimulator_amd.dist import strided_bounds
+    wl = synth.small_workload(40, 5, 7, 30, seed=21)
+    eng = util.engine_for(wl, synth.base_state(30)) if hasattr(util, "engine_for") else None
+    if eng is None:
+        eng = epi.GridEngine(epi.HyperParams(), wl["steps"], synth.base_state(30), wl["seed_idx"], [c.pop for c in wl["countries"]],
+                             wl["conn"], wl["profiles"], wl["betas"], wl["travel"], wl["t_arrive"], wl["t_peak"], True)
+    whole = eng.run()
+    G = 35
+    for ranks in (3, 8):
+        for r in range(ranks):
+            g0, stride, cnt, _ = strided_bounds(G, ranks, r)
+            part = eng.run_strided(g0, stride, cnt)
+            idx = np.arange(g0, G, stride)
+            np.testing.assert_array_equal(part["loss"], whole["loss"][idx])
+            np.testing.assert_array_equal(part["arrival"], whole["arrival"][idx])
+            np.testing.assert_array_equal(part["peak"], whole["peak"][idx])
+    with pytest.raises(epi.EpiError):
+        eng.run_strided(3, 8, 5)     # 3 + 4*8 = 35 is outside
+
+
 def test_grid_csr_input_equals_dense(epi):
     from epidemicsimulator_amd import synth
     countries, xy = synth.make_countries(300, 21)
