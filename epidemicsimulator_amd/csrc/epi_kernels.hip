@@ -44,9 +44,14 @@ __device__ __forceinline__ void record_error(int* sh_err, int code, int node, in
 //   C  apply inflow - export, advance t, arrival/peak metrics, world mass sums
 // The world mass totals of step t are compared by thread 0 during phase B of step t+1.
 // ---------------------------------------------------------------------------------------------
-template <int R>
-__global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs a) {
+// R = register slots per lane for one row (64 * R padded countries); W = waves per workgroup.  Threads below
+// 64 * R own one country each in the local and apply phases; every wave takes rows in the mobility phase, so
+// small worlds, whose episodes would otherwise run on one to four waves, get W >= R waves to hide the latency of
+// the search's dependent steps.
+template <int R, int W>
+__global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(W > R ? 8 : 1)))  /* small worlds: 64 registers, twice the resident waves */ void episode_dense_kernel(const EpisodeArgs a) {
     constexpr int NP = R * 64;
+    static_assert(W >= R, "every padded country needs a thread");
     __shared__ int32_t sh_s[NP], sh_i[NP], sh_r[NP], sh_d[NP], sh_v[NP];
     __shared__ double sh_cap[NP];
     __shared__ int32_t sh_expS[NP], sh_expI[NP];
@@ -67,19 +72,23 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
     const size_t eoff = (size_t)e * NP;
     const size_t plane = (size_t)a.count * NP;
     const bool real = tid < n;
+    const bool own = W == R || tid < NP;  // this thread holds a (padded) country
 
-    sh_s[tid] = a.st[0 * plane + eoff + tid];
-    sh_i[tid] = a.st[1 * plane + eoff + tid];
-    sh_r[tid] = a.st[2 * plane + eoff + tid];
-    sh_d[tid] = a.st[3 * plane + eoff + tid];
-    sh_v[tid] = a.st[4 * plane + eoff + tid];
-    sh_cap[tid] = a.cap[eoff + tid];
-    int32_t tcur = a.tcur[eoff + tid];
-    int32_t arrival = a.arrival[eoff + tid];
-    int32_t peak = a.peak[eoff + tid];
+    int32_t tcur = 0, arrival = 0, peak = 0;
+    if (own) {
+        sh_s[tid] = a.st[0 * plane + eoff + tid];
+        sh_i[tid] = a.st[1 * plane + eoff + tid];
+        sh_r[tid] = a.st[2 * plane + eoff + tid];
+        sh_d[tid] = a.st[3 * plane + eoff + tid];
+        sh_v[tid] = a.st[4 * plane + eoff + tid];
+        sh_cap[tid] = a.cap[eoff + tid];
+        tcur = a.tcur[eoff + tid];
+        arrival = a.arrival[eoff + tid];
+        peak = a.peak[eoff + tid];
+        sh_warm[0][tid].rho = 0.f;
+        sh_warm[1][tid].rho = 0.f;
+    }
     int32_t last_flow_s = 0, last_flow_i = 0;
-    sh_warm[0][tid].rho = 0.f;
-    sh_warm[1][tid].rho = 0.f;
     if (tid == 0) {
         sh_mass[0][0] = sh_mass[0][1] = sh_mass[1][0] = sh_mass[1][1] = 0ull;
         sh_err[0] = sh_err[1] = sh_err[2] = sh_err[3] = 0;
@@ -90,8 +99,10 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
     for (int t = a.t_begin; t < a.t_end; ++t) {
         // ------------------------------------------------------------------ phase A
         if (tid == 0) sh_next_row = 0;
-        sh_movS[tid] = 0u;
-        sh_movI[tid] = 0u;
+        if (own) {
+            sh_movS[tid] = 0u;
+            sh_movI[tid] = 0u;
+        }
         int32_t eS = 0, eI = 0;
         unsigned long long mass_local = 0ull;
         if (real) {
@@ -132,9 +143,11 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
             eI = export_count(max(0, o.i), my_sumw);
             mass_local = ta > 0 ? (unsigned long long)ta : 0ull;
         }
-        sh_expS[tid] = eS;
-        sh_expI[tid] = eI;
-        if (a.validate) {
+        if (own) {
+            sh_expS[tid] = eS;
+            sh_expI[tid] = eI;
+        }
+        if (a.validate && own) {
             const unsigned long long wsum = wave_sum_u64(mass_local);
             if (lane == 0) atomicAdd(&sh_mass[t & 1][0], wsum);
         }
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
             const long long tm = (long long)s3 + i3 + sh_r[tid] + sh_d[tid] + sh_v[tid];
             mass_move = tm > 0 ? (unsigned long long)tm : 0ull;
         }
-        if (a.validate) {
+        if (a.validate && own) {
             const unsigned long long wsum = wave_sum_u64(mass_move);
             if (lane == 0) atomicAdd(&sh_mass[t & 1][1], wsum);
         }
@@ -219,6 +232,7 @@ __global__ __launch_bounds__(R * 64) void episode_dense_kernel(const EpisodeArgs
             a.err[e * 4] = sh_err[0];
         }
     }
+    if (!own) return;
     a.st[0 * plane + eoff + tid] = sh_s[tid];
     a.st[1 * plane + eoff + tid] = sh_i[tid];
     a.st[2 * plane + eoff + tid] = sh_r[tid];
@@ -1012,12 +1026,15 @@ hipError_t launch_episode(const EpisodeArgs& a, hipStream_t s) {
         return hipGetLastError();
     }
     const dim3 grid((unsigned)a.count);
+    // waves per workgroup of the small-world variants (measured on the 200-country grid: 4 waves 1.22e9,
+    // 8 waves 1.27e9, 8 waves within 64 registers 1.53e9, 16 waves within 64 registers 1.66e9 country-steps/s)
+    constexpr int kW1 = 4, kW2 = 8, kW4 = 16;
     switch (a.npad / 64) {
-        case 1: hipLaunchKernelGGL(episode_dense_kernel<1>, grid, dim3(64), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(episode_dense_kernel<2>, grid, dim3(128), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(episode_dense_kernel<4>, grid, dim3(256), 0, s, a); break;
-        case 8: hipLaunchKernelGGL(episode_dense_kernel<8>, grid, dim3(512), 0, s, a); break;
-        case 16: hipLaunchKernelGGL(episode_dense_kernel<16>, grid, dim3(1024), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((episode_dense_kernel<1, kW1>), grid, dim3(64 * kW1), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((episode_dense_kernel<2, kW2>), grid, dim3(64 * kW2), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((episode_dense_kernel<4, kW4>), grid, dim3(64 * kW4), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((episode_dense_kernel<8, 8>), grid, dim3(512), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((episode_dense_kernel<16, 16>), grid, dim3(1024), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
