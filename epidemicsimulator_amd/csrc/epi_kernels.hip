@@ -1026,14 +1026,16 @@ hipError_t launch_episode(const EpisodeArgs& a, hipStream_t s) {
         return hipGetLastError();
     }
     const dim3 grid((unsigned)a.count);
-    // waves per workgroup of the small-world variants (measured on the 200-country grid: 4 waves 1.22e9,
-    // 8 waves 1.27e9, 8 waves within 64 registers 1.53e9, 16 waves within 64 registers 1.66e9 country-steps/s)
+    // waves per workgroup of the variants below 1,024 padded countries (measured on the 200-country grid: 4 waves
+    // 1.22e9, 8 waves 1.27e9, 8 waves within 64 registers 1.53e9, 16 waves within 64 registers 1.66e9 country-steps/s;
+    // 400 to 500 countries: 8 waves 1.10e9, 8 waves within 64 registers 1.33e9, 16 waves within 64 registers 1.46e9).
+    // The 16-slot variant cannot follow: within 64 registers it spills its keys and runs seven times slower.
     constexpr int kW1 = 4, kW2 = 8, kW4 = 16;
     switch (a.npad / 64) {
         case 1: hipLaunchKernelGGL((episode_dense_kernel<1, kW1>), grid, dim3(64 * kW1), 0, s, a); break;
         case 2: hipLaunchKernelGGL((episode_dense_kernel<2, kW2>), grid, dim3(64 * kW2), 0, s, a); break;
         case 4: hipLaunchKernelGGL((episode_dense_kernel<4, kW4>), grid, dim3(64 * kW4), 0, s, a); break;
-        case 8: hipLaunchKernelGGL((episode_dense_kernel<8, 8>), grid, dim3(512), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((episode_dense_kernel<8, 16>), grid, dim3(1024), 0, s, a); break;
         case 16: hipLaunchKernelGGL((episode_dense_kernel<16, 16>), grid, dim3(1024), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
