@@ -8,9 +8,10 @@
 // the contractions run on the vector ALUs, one output element per thread, sequential along the reduction
 // axis, weights read coalesced from L2.
 //
-// Division of labour: the replay ring and the shuffle of ReplayBuffer.sample (a sequential java.util.Random
-// walk over the whole buffer) live on the host; the sampled rows are staged in page-locked mapped memory
-// and everything from the three forward passes to the SGD step runs on the device.
+// Division of labour: the replay rings live in device memory (State.features of s and s2, reward, action, done per
+// transition); the shuffle of ReplayBuffer.sample (a sequential java.util.Random walk over the whole buffer) runs on
+// the host and only the sampled positions cross the bus; everything from the three forward passes to the SGD step
+// runs on the device.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -53,6 +54,14 @@ struct AgentHyperDev {
     double gamma, lr, clip_q, grad_clip;
 };
 
+// One stored transition (ReplayBuffer.scala:8) as the device keeps it: State.features of s and s2 (the only parts
+// of the states learn() reads), reward, action, done.
+struct RingRec {
+    double fs[kXStride], fs2[kXStride];
+    double r;
+    int32_t a, done;
+};
+
 // Arguments shared by the kernels of one call.  A "slot" is one agent taking part in the call.
 struct AgentsArgs {
     NetLayout nl;
@@ -64,10 +73,10 @@ struct AgentsArgs {
     const AgentHyperDev* hyper; // [n_agents]
     const int32_t* slot_agent;  // [slots]
     const int32_t* slot_rows;   // [slots] rows in use (need)
-    const double* X;            // [slots][2][Bp][kXStride]
-    const int32_t* act;         // [slots][Bp]
-    const double* rew;          // [slots][Bp]
-    const int32_t* done;        // [slots][Bp]
+    const RingRec* ring;        // replay rings of all agents, agent k's records from ring_off[k] on
+    const long long* ring_off;  // [n_agents]
+    const int32_t* idx;         // [slots][Bp] sampled ring positions (host memory, read over the bus), or NULL:
+    const double* X;            // [slots][kXStride] then: one directly staged feature row per slot (q-values)
     double* H1;                 // [slots][Bp][Hp]      class 0
     double* H2;                 // [slots][Bp][Hp]      class 0
     double* Q;                  // [slots][3][Bp][kOut] clamped outputs
@@ -86,34 +95,67 @@ __device__ inline double* net_ptr(const AgentsArgs& a, int agent, int which) {
 __device__ inline double clip_sym(double v, double c) { return isfinite(c) ? fmax(-c, fmin(c, v)) : v; }
 
 // Tiling of the forward and backward kernels: one lane per sample row (64 rows per workgroup), one wave per
-// tile of kTile hidden units.  A lane multiplies ITS activation by weights that are the same for the whole wave,
-// so the weights arrive through scalar loads (kTile contiguous doubles per step of the sum) and the vector ALU
-// does nothing but the ordered multiply-adds; activations sit in LDS as [unit][row], row stride kLS (odd, so the
-// row-major copies to and from global memory are conflict-free too).
+// tile of kTile = 16 hidden units.  A lane multiplies ITS activation by weights that are the same for the whole
+// wave, so the weights arrive through scalar loads (kTile contiguous doubles per step of the sum) and the vector
+// ALU does nothing but the ordered multiply-adds.  Activations pass through LDS as [unit][row] (row stride kLS,
+// odd, so the row-major copies to and from global memory are conflict-free too), kChunk units at a time: the
+// sums over a layer's inputs are taken chunk after chunk, in order, with the accumulators kept in registers.
+// A workgroup then needs 37 KB of LDS instead of 70 KB for a whole layer of 128 units, four of them fit a CU, and
+// the kernels, which wait on the scalar loads with 4 waves per SIMD (0.60 ms forward), run with 7.
 constexpr int kTileRows = 64;
 constexpr int kLS = kTileRows + 1;
+constexpr int kChunk = 64;
 
-__host__ __device__ inline size_t tile_lds_bytes(int Hp) { return ((size_t)Hp * kLS + (size_t)kXStride * kTileRows) * sizeof(double); }
+__host__ __device__ inline size_t tile_lds_bytes() { return ((size_t)kChunk * kLS + (size_t)kXStride * kTileRows) * sizeof(double); }
 
-// sh[unit][row] -> dst[row][unit] (row-major, stride Hp) for the rows of the tile that exist
-__device__ inline void store_rows(const double* sh, double* dst, int H, int Hp, int rows) {
-    for (int idx = threadIdx.x; idx < kTileRows * Hp; idx += blockDim.x) {
-        const int row = idx / Hp, unit = idx - row * Hp;
-        if (row < rows && unit < H) dst[(size_t)row * Hp + unit] = sh[unit * kLS + row];
+// sh[unit - u0][row] -> dst[row][unit] (row-major, stride Hp) for units u0 .. u0 + count - 1 and the rows that exist
+__device__ inline void store_chunk(const double* sh, double* dst, int u0, int count, int Hp, int rows) {
+    for (int idx = threadIdx.x; idx < kTileRows * kChunk; idx += blockDim.x) {
+        const int row = idx / kChunk, u = idx - row * kChunk;
+        if (row < rows && u < count) dst[(size_t)row * Hp + u0 + u] = sh[u * kLS + row];
     }
 }
 
-// acc[u] = sum over j < K, in order, of W[j * ldw + u] * act[j * kLS] (first product starts the sum, as .sum does)
+// acc[u] += sum over j < K, in order, of W[j * ldw + u] * act[j * kLS]; with `first` the first product starts the
+// sums (as .sum does)
 template <int kTile>
-__device__ inline void ordered_tile(const double* __restrict__ W, int ldw, const double* act, int K, double (&acc)[kTile]) {
-    double h = act[0];
+__device__ inline void ordered_tile(const double* __restrict__ W, int ldw, const double* act, int K, bool first,
+                                    double (&acc)[kTile]) {
+    int j = 0;
+    if (first) {
+        const double h = act[0];
 #pragma unroll
-    for (int u = 0; u < kTile; ++u) acc[u] = W[u] * h;
+        for (int u = 0; u < kTile; ++u) acc[u] = W[u] * h;
+        j = 1;
+    }
 #pragma unroll 2
-    for (int j = 1; j < K; ++j) {
-        h = act[j * kLS];
+    for (; j < K; ++j) {
+        const double h = act[j * kLS];
 #pragma unroll
         for (int u = 0; u < kTile; ++u) acc[u] = acc[u] + W[(size_t)j * ldw + u] * h;
+    }
+}
+
+// First hidden layer for the lane's row and units c0 + u0 .. c0 + u0 + N - 1 of a chunk: relu(W1 x + b1) into LDS.
+template <int N>
+__device__ inline void first_layer_units(const double* __restrict__ net, const NetLayout& nl, int c0, int u0,
+                                         const double* sh_x, double* sh_h, int lane) {
+    const double* __restrict__ W1t = net + nl.w1t() + c0 + u0;
+    const double* __restrict__ b1 = net + nl.b1() + c0 + u0;
+    double z[N];
+    double x = sh_x[lane];
+#pragma unroll
+    for (int u = 0; u < N; ++u) z[u] = W1t[u] * x;
+#pragma unroll
+    for (int j = 1; j < kIn; ++j) {
+        x = sh_x[j * kTileRows + lane];
+#pragma unroll
+        for (int u = 0; u < N; ++u) z[u] = z[u] + W1t[(size_t)j * nl.Hp + u] * x;
+    }
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const double v = z[u] + b1[u];
+        sh_h[(u0 + u) * kLS + lane] = v > 0 ? v : 0.0;
     }
 }
 
@@ -124,49 +166,52 @@ template <int kTile>
 __global__ void __launch_bounds__(1024) agents_forward_kernel(AgentsArgs a, const double* __restrict__ nets) {
     extern __shared__ double smem[];
     double* sh_x = smem;                          // [kXStride][64]
-    double* sh_h = smem + kXStride * kTileRows;   // [Hp][kLS]
+    double* sh_h = smem + kXStride * kTileRows;   // [kChunk][kLS]
     const int slot = blockIdx.y, B = a.slot_rows[slot];
     const int groups = a.Bp / kTileRows;
     const int cls = blockIdx.x / groups, k0 = (blockIdx.x % groups) * kTileRows;
     if (k0 >= B) return;
     const int H = a.nl.H, Hp = a.nl.Hp;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i0 = wave * kTile;
+    const int n_waves = blockDim.x >> 6;
     const int agent = a.slot_agent[slot];
     const double* __restrict__ net = nets + ((size_t)agent * 2 + a.net_of_class[cls]) * a.nl.size();
     const double clip_q = a.hyper[agent].clip_q;
     const int rows = min(kTileRows, B - k0);
     const size_t row0 = (size_t)slot * a.Bp + k0;
-    const double* X = a.X + (((size_t)slot * 2 + a.x_of_class[cls]) * a.Bp + k0) * kXStride;
+    const RingRec* ring = a.ring + a.ring_off[agent];
     for (int idx = threadIdx.x; idx < kTileRows * kXStride; idx += blockDim.x) {
         const int row = idx / kXStride, j = idx % kXStride;
-        const double x = row < rows ? X[idx] : 0.0;   // staged rows sit in host memory: read once, kept on the device
+        double x = 0.0;
+        if (row < rows) {
+            if (a.idx) {
+                const RingRec& rec = ring[a.idx[row0 + row]];
+                x = a.x_of_class[cls] ? rec.fs2[j] : rec.fs[j];
+            } else {
+                x = a.X[(size_t)slot * kXStride + j];
+            }
+        }
         sh_x[j * kTileRows + row] = x;
-        if (cls == 0) a.X0d[row0 * kXStride + idx] = x;
+        if (cls == 0) a.X0d[row0 * kXStride + idx] = x;   // gathered rows of s, row-major, for the gradient kernels
     }
-    __syncthreads();
     double acc[kTile];
-    if (i0 < H) {
-        const double* __restrict__ W1t = net + a.nl.w1t() + i0;
-        double x = sh_x[lane];
-#pragma unroll
-        for (int u = 0; u < kTile; ++u) acc[u] = W1t[u] * x;
-#pragma unroll
-        for (int j = 1; j < kIn; ++j) {
-            x = sh_x[j * kTileRows + lane];
-#pragma unroll
-            for (int u = 0; u < kTile; ++u) acc[u] = acc[u] + W1t[(size_t)j * Hp + u] * x;
+    // first layer, kChunk units at a time, each chunk consumed by the second layer's sums right away
+    for (int c0 = 0; c0 < H; c0 += kChunk) {
+        const int cn = min(kChunk, H - c0);
+        __syncthreads();  // sh_x written / the previous chunk read by every wave
+        // every wave takes an equal run of the chunk's units (weights padded with zeros past H)
+        switch (n_waves) {
+            case 4: first_layer_units<16>(net, a.nl, c0, wave * 16, sh_x, sh_h, lane); break;
+            case 8: first_layer_units<8>(net, a.nl, c0, wave * 8, sh_x, sh_h, lane); break;
+            case 16: first_layer_units<4>(net, a.nl, c0, wave * 4, sh_x, sh_h, lane); break;
+            default:
+                for (int uu = wave; uu < kChunk; uu += n_waves) first_layer_units<1>(net, a.nl, c0, uu, sh_x, sh_h, lane);
         }
-        const double* __restrict__ b1 = net + a.nl.b1() + i0;
-#pragma unroll
-        for (int u = 0; u < kTile; ++u) {
-            const double z = acc[u] + b1[u];
-            sh_h[(i0 + u) * kLS + lane] = z > 0 ? z : 0.0;
-        }
+        __syncthreads();
+        if (cls == 0) store_chunk(sh_h, a.H1 + row0 * Hp, c0, cn, Hp, rows);
+        if (i0 < H) ordered_tile(net + a.nl.w2t() + (size_t)c0 * Hp + i0, Hp, sh_h + lane, cn, c0 == 0, acc);
     }
-    __syncthreads();
-    if (cls == 0) store_rows(sh_h, a.H1 + row0 * Hp, H, Hp, rows);
     if (i0 < H) {
-        ordered_tile(net + a.nl.w2t() + i0, Hp, sh_h + lane, H, acc);
         const double* __restrict__ b2 = net + a.nl.b2() + i0;
 #pragma unroll
         for (int u = 0; u < kTile; ++u) {
@@ -174,21 +219,37 @@ __global__ void __launch_bounds__(1024) agents_forward_kernel(AgentsArgs a, cons
             acc[u] = z > 0 ? z : 0.0;
         }
     }
-    __syncthreads();  // every wave has finished reading the first hidden layer
-    if (i0 < H) {
+    // output layer: the second hidden layer passes through LDS chunk by chunk; wave w sums outputs w and
+    // w + n_waves (a workgroup has at least four waves)
+    double y[2] = {0.0, 0.0};
+    for (int c0 = 0; c0 < H; c0 += kChunk) {
+        const int cn = min(kChunk, H - c0);
+        __syncthreads();  // the previous contents read by every wave
+        if (i0 >= c0 && i0 < c0 + kChunk && i0 < H) {
 #pragma unroll
-        for (int u = 0; u < kTile; ++u) sh_h[(i0 + u) * kLS + lane] = acc[u];
+            for (int u = 0; u < kTile; ++u) sh_h[(i0 - c0 + u) * kLS + lane] = acc[u];
+        }
+        __syncthreads();
+        if (cls == 0) store_chunk(sh_h, a.H2 + row0 * Hp, c0, cn, Hp, rows);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int o = wave + q * n_waves;
+            if (o < kOut) {
+                const double* __restrict__ W3 = net + a.nl.w3() + (size_t)o * Hp + c0;
+                int j = 0;
+                if (c0 == 0) { y[q] = W3[0] * sh_h[lane]; j = 1; }
+#pragma unroll 16
+                for (; j < cn; ++j) y[q] = y[q] + W3[j] * sh_h[j * kLS + lane];
+            }
+        }
     }
-    __syncthreads();
-    if (cls == 0) store_rows(sh_h, a.H2 + row0 * Hp, H, Hp, rows);
-    const int n_waves = blockDim.x >> 6;
-    for (int o = wave; o < kOut; o += n_waves) {
-        const double* __restrict__ W3 = net + a.nl.w3() + (size_t)o * Hp;
-        double y = W3[0] * sh_h[lane];
-#pragma unroll 4
-        for (int j = 1; j < H; ++j) y = y + W3[j] * sh_h[j * kLS + lane];
-        y = y + net[a.nl.b3() + o];
-        if (lane < rows) a.Q[(((size_t)slot * 3 + cls) * a.Bp + k0 + lane) * kOut + o] = clip_sym(y, clip_q);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int o = wave + q * n_waves;
+        if (o < kOut) {
+            const double yo = y[q] + net[a.nl.b3() + o];
+            if (lane < rows) a.Q[(((size_t)slot * 3 + cls) * a.Bp + k0 + lane) * kOut + o] = clip_sym(yo, clip_q);
+        }
     }
 }
 
@@ -200,7 +261,7 @@ __global__ void __launch_bounds__(1024) agents_backward_kernel(AgentsArgs a, con
     extern __shared__ double smem[];
     double* sh_err = smem;                        // [64]
     int* sh_act = reinterpret_cast<int*>(smem + kTileRows);  // [64]
-    double* sh_d = smem + kXStride * kTileRows;   // [Hp][kLS]
+    double* sh_d = smem + kXStride * kTileRows;   // [kChunk][kLS]
     const int slot = blockIdx.y, B = a.slot_rows[slot];
     const int k0 = blockIdx.x * kTileRows;
     if (k0 >= B) return;
@@ -218,18 +279,19 @@ __global__ void __launch_bounds__(1024) agents_backward_kernel(AgentsArgs a, con
         if (lane < rows) {
             const size_t row = row0 + lane;
             const double* q = a.Q + (((size_t)slot * 3 + 0) * a.Bp + k) * kOut;
-            act = a.act[row];
+            const RingRec& rec = a.ring[a.ring_off[agent] + a.idx[row]];
+            act = rec.a;
             a.ACTd[row] = act;
             double tgt;
-            if (a.done[row]) {
-                tgt = fmax(-hp.clip_q, fmin(hp.clip_q, a.rew[row]));
+            if (rec.done) {
+                tgt = fmax(-hp.clip_q, fmin(hp.clip_q, rec.r));
             } else {
                 const double* qn = a.Q + (((size_t)slot * 3 + 1) * a.Bp + k) * kOut;
                 const double* qt = a.Q + (((size_t)slot * 3 + 2) * a.Bp + k) * kOut;
                 int best = 0;  // zipWithIndex.maxBy(_._1): the first maximum
                 for (int o = 1; o < kOut; ++o)
                     if (qn[o] > qn[best]) best = o;
-                tgt = fmax(-hp.clip_q, fmin(hp.clip_q, a.rew[row] + hp.gamma * qt[best]));
+                tgt = fmax(-hp.clip_q, fmin(hp.clip_q, rec.r + hp.gamma * qt[best]));
             }
             err = q[act] - tgt;
             a.ERR[row] = err;
@@ -237,36 +299,40 @@ __global__ void __launch_bounds__(1024) agents_backward_kernel(AgentsArgs a, con
         sh_err[lane] = err;
         sh_act[lane] = act;
     }
-    // second hidden layer's activations of the tile, [unit][row]
-    for (int idx = threadIdx.x; idx < kTileRows * Hp; idx += blockDim.x) {
-        const int row = idx / Hp, unit = idx - row * Hp;
-        sh_d[unit * kLS + row] = row < rows ? a.H2[(row0 + row) * Hp + unit] : 0.0;
-    }
-    __syncthreads();
-    if (i0 < H) {
-        const double err = sh_err[lane];
-        const double* W3a = net + a.nl.w3() + (size_t)sh_act[lane] * Hp + i0;
-#pragma unroll
-        for (int u = 0; u < kTile; ++u) {
-            const double dh = W3a[u] * err;
-            sh_d[(i0 + u) * kLS + lane] = lane < rows ? dh * sh_d[(i0 + u) * kLS + lane] : 0.0;
-        }
-    }
-    __syncthreads();
-    store_rows(sh_d, a.DZ2 + row0 * Hp, H, Hp, rows);
     double acc[kTile];
-    if (i0 < H) ordered_tile(net + a.nl.w2() + i0, Hp, sh_d + lane, H, acc);  // dh1(j) = sum_i W2(i)(j) * dz2(i)
-    __syncthreads();  // every wave has finished reading dz2
-    if (i0 < H) {
-#pragma unroll
-        for (int u = 0; u < kTile; ++u) sh_d[(i0 + u) * kLS + lane] = acc[u];
+    // dz2 of kChunk units at a time: formed in LDS from the stored activations, written out, and consumed by the
+    // sums dh1(j) = sum_i W2(i)(j) * dz2(i) right away
+    for (int c0 = 0; c0 < H; c0 += kChunk) {
+        const int cn = min(kChunk, H - c0);
+        __syncthreads();  // sh_err, sh_act written / the previous chunk read by every wave
+        for (int idx = threadIdx.x; idx < kTileRows * kChunk; idx += blockDim.x) {
+            const int row = idx / kChunk, u = idx - row * kChunk;
+            double dz = 0.0;
+            if (row < rows && u < cn) {
+                const double dh = net[a.nl.w3() + (size_t)sh_act[row] * Hp + c0 + u] * sh_err[row];
+                dz = dh * a.H2[(row0 + row) * Hp + c0 + u];
+                a.DZ2[(row0 + row) * Hp + c0 + u] = dz;
+            }
+            sh_d[u * kLS + row] = dz;
+        }
+        __syncthreads();
+        if (i0 < H) ordered_tile(net + a.nl.w2() + (size_t)c0 * Hp + i0, Hp, sh_d + lane, cn, c0 == 0, acc);
     }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < kTileRows * Hp; idx += blockDim.x) {
-        const int row = idx / Hp, unit = idx - row * Hp;
-        if (row < rows && unit < H) {
-            const size_t g = (row0 + row) * Hp + unit;
-            a.DZ1[g] = sh_d[unit * kLS + row] * a.H1[g];
+    // dz1 = dh1 * relu(z1), written row-major through LDS, one chunk of units at a time
+    for (int c0 = 0; c0 < H; c0 += kChunk) {
+        const int cn = min(kChunk, H - c0);
+        __syncthreads();
+        if (i0 >= c0 && i0 < c0 + kChunk && i0 < H) {
+#pragma unroll
+            for (int u = 0; u < kTile; ++u) sh_d[(i0 - c0 + u) * kLS + lane] = acc[u];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < kTileRows * kChunk; idx += blockDim.x) {
+            const int row = idx / kChunk, u = idx - row * kChunk;
+            if (row < rows && u < cn) {
+                const size_t g = (row0 + row) * Hp + c0 + u;
+                a.DZ1[g] = sh_d[u * kLS + row] * a.H1[g];
+            }
         }
     }
 }
@@ -369,10 +435,11 @@ __global__ void __launch_bounds__(256) agents_grad_small_kernel(AgentsArgs a) {
     net[dst] -= hp.lr * clip_sym(acc * scale, hp.grad_clip);
 }
 
-struct Transition {
-    double fs[kIn], fs2[kIn], r;
-    int32_t a, done;
-};
+// DDQNAgent.observe -> ReplayBuffer.push (ReplayBuffer.scala:15-17): staged records into their ring slots.
+__global__ void __launch_bounds__(64) agents_push_kernel(RingRec* ring, const RingRec* staged, const long long* dst, int count) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < count) ring[dst[k]] = staged[k];
+}
 
 // State.features (env.scala:26-30)
 void features(const epi_state& s, double* f) {
@@ -383,19 +450,20 @@ void features(const epi_state& s, double* f) {
     f[6] = (double)s.t / (double)std::max(1, s.t_max);
 }
 
-struct Replay {  // ReplayBuffer.scala:10-22
-    std::vector<Transition> buf;
-    int capacity = 0, idx = 0;
+struct Replay {  // ReplayBuffer.scala:10-22: the bookkeeping; the records themselves live in the device ring
+    int capacity = 0, size = 0, idx = 0;
     JavaRandom rnd{123};
     std::vector<int32_t> perm;
-    void push(const Transition& t) {
-        if ((int)buf.size() < capacity) buf.push_back(t);
-        else { buf[idx] = t; idx = (idx + 1) % capacity; }
+    int push() {  // the slot the next transition goes to
+        if (size < capacity) return size++;
+        const int at = idx;
+        idx = (idx + 1) % capacity;
+        return at;
     }
     // positions of rnd.shuffle(buf).take(n): scala.util.Random.shuffle copies the buffer and, for m from its length
     // down to 2, swaps element m-1 with element nextInt(m)
     const int32_t* sample() {
-        const int len = (int)buf.size();
+        const int len = size;
         perm.resize((size_t)len);
         for (int i = 0; i < len; ++i) perm[i] = i;
         for (int m = len; m >= 2; --m) std::swap(perm[m - 1], perm[rnd.nextInt(m)]);
@@ -414,8 +482,9 @@ struct epi_agents {
     std::vector<epi_learn_hyper> hp;
     std::vector<Replay> replay;
     std::vector<double> ema;
-    DevBuf nets, hyper, H1, H2, Q, DZ2, DZ1, ERR, X0d, ACTd;
-    PinBuf slot_agent, slot_rows, X, act, rew, done, loss;
+    DevBuf nets, hyper, H1, H2, Q, DZ2, DZ1, ERR, X0d, ACTd, ring, ring_off;
+    PinBuf slot_agent, slot_rows, X, idx, loss, push_rec, push_dst;
+    std::vector<long long> h_ring_off;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
@@ -431,8 +500,8 @@ struct epi_agents {
         a.nl = nl; a.Bp = Bp;
         a.nets = nets.as<double>(); a.hyper = hyper.as<AgentHyperDev>();
         a.slot_agent = slot_agent.on_device<int32_t>(); a.slot_rows = slot_rows.on_device<int32_t>();
-        a.X = X.on_device<double>(); a.act = act.on_device<int32_t>(); a.rew = rew.on_device<double>();
-        a.done = done.on_device<int32_t>();
+        a.ring = ring.as<RingRec>(); a.ring_off = ring_off.as<long long>();
+        a.idx = idx.on_device<int32_t>(); a.X = X.on_device<double>();
         a.H1 = H1.as<double>(); a.H2 = H2.as<double>(); a.Q = Q.as<double>(); a.DZ2 = DZ2.as<double>();
         a.DZ1 = DZ1.as<double>(); a.ERR = ERR.as<double>(); a.X0d = X0d.as<double>(); a.ACTd = ACTd.as<int32_t>();
         a.loss = loss.on_device<double>();
@@ -510,18 +579,21 @@ EPI_API epi_agents* epi_agents_create(int32_t n_agents, const epi_learn_hyper* h
     std::vector<AgentHyperDev> hd((size_t)n_agents);
     for (int k = 0; k < n_agents; ++k) hd[k] = {hp[k].gamma, hp[k].lr, hp[k].clip_q, hp[k].grad_clip};
     const size_t rows = (size_t)n_agents * g->Bp, Hp = (size_t)g->nl.Hp;
+    long long ring_total = 0;
+    for (int k = 0; k < n_agents; ++k) { g->h_ring_off.push_back(ring_total); ring_total += hp[k].replay_capacity; }
     if (!ok(g->nets.upload(all), "networks") || !ok(g->hyper.upload(hd), "hyper") ||
         !ok(g->H1.ensure(rows * Hp * 8), "H1") || !ok(g->H2.ensure(rows * Hp * 8), "H2") ||
         !ok(g->Q.ensure(rows * 3 * kOut * 8), "Q") || !ok(g->DZ2.ensure(rows * Hp * 8), "DZ2") ||
         !ok(g->DZ1.ensure(rows * Hp * 8), "DZ1") || !ok(g->ERR.ensure(rows * 8), "ERR") ||
         !ok(g->X0d.ensure(rows * kXStride * 8), "X0d") || !ok(g->ACTd.ensure(rows * 4), "ACTd") ||
         !ok(g->slot_agent.ensure((size_t)n_agents * 4), "slots") || !ok(g->slot_rows.ensure((size_t)n_agents * 4), "slots") ||
-        !ok(g->X.ensure(rows * 2 * kXStride * 8), "X") || !ok(g->act.ensure(rows * 4), "act") ||
-        !ok(g->rew.ensure(rows * 8), "rew") || !ok(g->done.ensure(rows * 4), "done") ||
+        !ok(g->X.ensure((size_t)n_agents * kXStride * 8), "X") || !ok(g->idx.ensure(rows * 4), "idx") ||
+        !ok(g->push_rec.ensure((size_t)n_agents * sizeof(RingRec)), "push") || !ok(g->push_dst.ensure((size_t)n_agents * 8), "push") ||
+        !ok(g->ring.ensure((size_t)ring_total * sizeof(RingRec)), "replay rings") || !ok(g->ring_off.upload(g->h_ring_off), "replay rings") ||
         !ok(g->loss.ensure((size_t)n_agents * 8), "loss") ||
         !ok(hipMemset(g->DZ2.p, 0, rows * Hp * 8), "clear") ||  // columns past H are read by the gradient kernel
-        !ok(hipFuncSetAttribute(reinterpret_cast<const void*>(agents_forward_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(256)), "lds") ||
-        !ok(hipFuncSetAttribute(reinterpret_cast<const void*>(agents_backward_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(256)), "lds") ||
+        !ok(hipFuncSetAttribute(reinterpret_cast<const void*>(agents_forward_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes()), "lds") ||
+        !ok(hipFuncSetAttribute(reinterpret_cast<const void*>(agents_backward_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes()), "lds") ||
         !ok(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking), "stream") ||
         !ok(hipEventCreate(&g->ev0), "event") || !ok(hipEventCreate(&g->ev1), "event"))
         return nullptr;
@@ -540,19 +612,29 @@ EPI_API int32_t epi_agents_observe(epi_agents* g, const int32_t* ids, int32_t co
                                    const double* r, const epi_state* s2, const uint8_t* done) {
     if (!g || !s || !a || !r || !s2 || !done) return fail(EPI_ERR_BAD_ARGUMENT, "agents_observe: null argument");
     if (int32_t rc = check_ids(g, ids, count)) return rc;
-    for (int k = 0; k < count; ++k) {
+    if (count == 0) return EPI_OK;
+    for (int k = 0; k < count; ++k)
         if (a[k] < 0 || a[k] >= kOut) return fail(EPI_ERR_BAD_ARGUMENT, "agents_observe: action %d outside [0,%d)", a[k], kOut);
-        Transition t;
-        features(s[k], t.fs); features(s2[k], t.fs2);
-        t.a = a[k]; t.r = r[k]; t.done = done[k] ? 1 : 0;
-        g->replay[ids ? ids[k] : k].push(t);
+    if (int32_t rc = use_device(g->device)) return rc;
+    RingRec* rec = g->push_rec.as<RingRec>();
+    long long* dst = g->push_dst.as<long long>();
+    for (int k = 0; k < count; ++k) {
+        const int id = ids ? ids[k] : k;
+        features(s[k], rec[k].fs); features(s2[k], rec[k].fs2);
+        rec[k].fs[7] = rec[k].fs2[7] = 0.0;
+        rec[k].r = r[k]; rec[k].a = a[k]; rec[k].done = done[k] ? 1 : 0;
+        dst[k] = g->h_ring_off[id] + g->replay[id].push();
     }
+    hipLaunchKernelGGL(agents_push_kernel, dim3((count + 63) / 64), dim3(64), 0, g->stream, g->ring.as<RingRec>(),
+                       g->push_rec.on_device<RingRec>(), g->push_dst.on_device<long long>(), count);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g->stream));  // the staging arrays are free again
     return EPI_OK;
 }
 
 EPI_API int32_t epi_agents_replay_size(epi_agents* g, int32_t* sizes) {
     if (!g || !sizes) return fail(EPI_ERR_BAD_ARGUMENT, "agents_replay_size: null argument");
-    for (int k = 0; k < g->n; ++k) sizes[k] = (int32_t)g->replay[k].buf.size();
+    for (int k = 0; k < g->n; ++k) sizes[k] = g->replay[k].size;
     return EPI_OK;
 }
 
@@ -560,7 +642,7 @@ EPI_API int32_t epi_agents_sample(epi_agents* g, int32_t agent, int32_t n, int32
     if (!g || !out || !taken || agent < 0 || agent >= g->n || n < 0) return fail(EPI_ERR_BAD_ARGUMENT, "agents_sample: bad argument");
     Replay& rp = g->replay[agent];
     const int32_t* p = rp.sample();
-    *taken = std::min<int32_t>(n, (int32_t)rp.buf.size());
+    *taken = std::min<int32_t>(n, rp.size);
     std::copy(p, p + *taken, out);
     return EPI_OK;
 }
@@ -580,7 +662,7 @@ EPI_API int32_t epi_agents_learn(epi_agents* g, const int32_t* ids, int32_t coun
         if (batch[k] <= 0 || grad_accum[k] <= 0) return fail(EPI_ERR_BAD_ARGUMENT, "agents_learn: batch and grad_accum must be positive");
         const int64_t need64 = std::max<int64_t>((int64_t)batch[k] * grad_accum[k], batch[k]);
         loss[k] = 0.0;
-        if ((int64_t)g->replay[id].buf.size() < need64) continue;
+        if ((int64_t)g->replay[id].size < need64) continue;
         if (need64 > g->hp[id].max_need)
             return fail(EPI_ERR_BAD_ARGUMENT, "agents_learn: agent %d needs %lld samples, the handle was created for %d", id, (long long)need64, g->hp[id].max_need);
         slot_of[k] = slots;
@@ -590,21 +672,11 @@ EPI_API int32_t epi_agents_learn(epi_agents* g, const int32_t* ids, int32_t coun
     if (slots > 0) {
         const int Bp = g->Bp;
         // The shuffle walks the whole buffer with a sequential generator (ReplayBuffer.scala:21-22): agents are
-        // independent, so their shuffles and row gathers run on a few host threads.
+        // independent, so their shuffles run on a few host threads.  Only the sampled positions cross the bus.
         auto stage = [&](int sl) {
             const int id = sa[sl], need = sr[sl];
-            Replay& rp = g->replay[id];
-            const int32_t* p = rp.sample();
-            double* X0 = g->X.as<double>() + ((size_t)sl * 2 + 0) * Bp * kXStride;
-            double* X1 = g->X.as<double>() + ((size_t)sl * 2 + 1) * Bp * kXStride;
-            for (int q = 0; q < need; ++q) {
-                const Transition& t = rp.buf[(size_t)p[q]];
-                std::memcpy(X0 + (size_t)q * kXStride, t.fs, sizeof t.fs); X0[(size_t)q * kXStride + 7] = 0.0;
-                std::memcpy(X1 + (size_t)q * kXStride, t.fs2, sizeof t.fs2); X1[(size_t)q * kXStride + 7] = 0.0;
-                g->act.as<int32_t>()[(size_t)sl * Bp + q] = t.a;
-                g->rew.as<double>()[(size_t)sl * Bp + q] = t.r;
-                g->done.as<int32_t>()[(size_t)sl * Bp + q] = t.done;
-            }
+            const int32_t* p = g->replay[id].sample();
+            std::memcpy(g->idx.as<int32_t>() + (size_t)sl * Bp, p, sizeof(int32_t) * (size_t)need);
         };
         const int n_threads = std::max(1, std::min({slots / 4, 16, (int)std::thread::hardware_concurrency()}));
         if (n_threads == 1) {
@@ -621,7 +693,7 @@ EPI_API int32_t epi_agents_learn(epi_agents* g, const int32_t* ids, int32_t coun
         a.x_of_class[0] = 0; a.x_of_class[1] = 1; a.x_of_class[2] = 1;
         const int Hp = g->nl.Hp, H = g->nl.H;
         if (g->timing) HIP_TRY(hipEventRecord(g->ev0, g->stream));
-        const size_t lds = tile_lds_bytes(Hp);
+        const size_t lds = tile_lds_bytes();
         // 16 hidden units per wave: tiles of 8 (twice the waves) measured slower on the default width
         hipLaunchKernelGGL(agents_forward_kernel<16>, dim3(3 * Bp / kTileRows, slots), dim3(Hp / 16 * 64), lds, g->stream, a, a.nets);
         hipLaunchKernelGGL(agents_backward_kernel<16>, dim3(Bp / kTileRows, slots), dim3(Hp / 16 * 64), lds, g->stream, a, a.nets);
@@ -669,14 +741,15 @@ EPI_API int32_t epi_agents_q_values(epi_agents* g, const int32_t* ids, int32_t c
     for (int k = 0; k < count; ++k) {
         g->slot_agent.as<int32_t>()[k] = ids ? ids[k] : k;
         g->slot_rows.as<int32_t>()[k] = 1;
-        double* X0 = g->X.as<double>() + ((size_t)k * 2 + 0) * Bp * kXStride;
+        double* X0 = g->X.as<double>() + (size_t)k * kXStride;
         features(s[k], X0); X0[7] = 0.0;
     }
     AgentsArgs a = g->args();
     a.n_classes = 1;
+    a.idx = nullptr;  // one directly staged row per slot
     a.net_of_class[0] = use_target ? 1 : 0; a.x_of_class[0] = 0;
     // class 0 also writes the hidden activations of row 0 of each slot: scratch no later call relies on
-    hipLaunchKernelGGL(agents_forward_kernel<16>, dim3(1, count), dim3(g->nl.Hp / 16 * 64), tile_lds_bytes(g->nl.Hp), g->stream, a, a.nets);
+    hipLaunchKernelGGL(agents_forward_kernel<16>, dim3(1, count), dim3(g->nl.Hp / 16 * 64), tile_lds_bytes(), g->stream, a, a.nets);
     HIP_TRY(hipGetLastError());
     std::vector<double> out((size_t)count * kOut);
     for (int k = 0; k < count; ++k)
