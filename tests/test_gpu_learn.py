@@ -66,6 +66,7 @@ def _assert_same_networks(agents, learners):
     (100, 8, 1, 500, 64),      # width off the 64 grid
     (128, 128, 4, 50000, 700),  # the reference's defaults: 512 samples per learn
     (256, 10, 3, 64, 64),      # widest supported, need not a multiple of 4
+    (130, 6, 2, 40, 50),       # 192 padded units: twelve waves, three chunks of activations
 ])
 def test_learn_matches_oracle(epi, hidden, batch, accum, capacity, pushes):
     rng = np.random.default_rng(hidden + batch)
