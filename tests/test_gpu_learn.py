@@ -232,3 +232,23 @@ def test_world_step_one_with_learning_agents(epi):
     out = w.step_one_greedy(400)
     acts = [int(np.argmax(ow.learner(k).q_values(want_s[k]))) for k in range(w.n)]
     assert [nd.last_a for nd in w.nodes] == acts
+
+
+def test_empty_calls_are_no_ops(epi):
+    """No agents listed: observe, learn and q_values return without touching anything."""
+    hp = epi.HyperParams(hidden=16, batch_size=2, replay_capacity=8)
+    agents = epi.Agents([hp, hp], max_grad_accum=2)
+    before = agents.weights(1)
+    agents.observe([], [])
+    loss, ema = agents.learn([], [], 2, [])
+    assert len(loss) == 0 and len(ema) == 0
+    q, g = agents.q_values([], [])
+    assert q.shape == (0, 8) and len(g) == 0
+    assert list(agents.replay_size()) == [0, 0]
+    assert list(agents.sample(0, 3)) == []
+    for x, y in zip(before, agents.weights(1)):
+        assert np.array_equal(x, y)
+    with pytest.raises(epi.EpiError):
+        agents.observe([epi.Transition(epi.State(1, 0, 0, 0, 0, 1, 0, 1, 1), 9, 0.0, epi.State(1, 0, 0, 0, 0, 1, 1, 1, 1), False)], [0])
+    with pytest.raises(epi.EpiError):
+        agents.q_values([epi.State(1, 0, 0, 0, 0, 1, 0, 1, 1)] * 2, [1, 1])   # an agent listed twice
