@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Randomised differential soak of the batched world step (epi_world_step): random world sizes and graphs, random
+environments, actions and noise, engine against the oracle's WorldToy step; states, rewards and flows with ==.
+   python tools/soak_world.py [seconds] [seed]    (needs a GPU)"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+import epidemicsimulator_amd as E
+from epidemicsimulator_amd import synth
+from oracle import oracle_lib as O
+from tests import util
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+    O.build()
+    t0 = time.time()
+    cases = 0
+    while time.time() - t0 < budget:
+        sparse = rng.random() < 0.25
+        n = int(rng.integers(1025, 1600)) if sparse else int(rng.choice([1, 2, 6, 15, 16, 17, 40, 64, 65, 128, 129, 200, 256, 257, 400, 512, 513, 700]))
+        seed = int(rng.integers(1, 1 << 30))
+        countries, xy = synth.make_countries(n, seed)
+        if sparse:
+            conn = synth.gravity_csr(countries, xy, seed, mean_degree=float(rng.choice([3.0, 9.0, 20.0])))
+        elif n > 1:
+            conn = synth.gravity_dense(countries, xy)
+        else:
+            conn = np.zeros((1, 1))
+        batch = int(rng.integers(1, 4))
+        t_max = int(rng.integers(5, 200))
+        base = E.State(0, 0, 0, 0, 0, float(rng.integers(100, 50_000)), 0, t_max, 42)
+        envs = [E.EpidemicEnv(0.1 + 0.5 * rng.random(), 0.05 + 0.2 * rng.random(), 0.002 + 0.02 * rng.random(), 0.1 * rng.random(), 5.0,
+                              0.5 * rng.random(), c.name, 100 + k, profile=c) for k, c in enumerate(countries)]
+        it = iter(envs)
+        seed_idx = int(rng.integers(0, n))
+        w = E.WorldToy(E.HyperParams(), base, seed_idx, conn, make_env_for=lambda name, pop: next(it), validate=True,
+                       countries=countries, batch=batch, learning=False)
+        ow = O.World([c.pop for c in countries], util.dense_of(conn, n), seed_idx, util.oracle_state(base),
+                     [O.EnvParams(e.base_beta, e.base_gamma, e.base_ifr, e.noise, e.reward_clip, e.risk_factor) for e in envs],
+                     [util.prof_dict(e.country_profile) for e in envs], [e.seed for e in envs], validate=True)
+        steps = int(rng.integers(2, 7))
+        for step in range(steps):
+            acts = rng.integers(-1, 10, (batch, n))           # out-of-range ids are clamped (Action.fromId)
+            gauss = rng.normal(size=(batch, n)) * rng.choice([0.3, 1.0, 3.0])
+            acts[1:], gauss[1:] = acts[0], gauss[0]          # the instances share inputs, so they must stay equal
+            states, rewards = w.step_arrays(acts, gauss, t_max)
+            o_r, o_ms, o_mi = ow.step_given(np.clip(acts[0], 0, 7), gauss[0], t_max)
+            assert ow.error()[0] == 0
+            want = ow.states()
+            ms, mi = w.last_flows()
+            for b in range(batch):
+                for f, g in (("s", "s"), ("i", "i"), ("r", "r"), ("d", "d"), ("v", "v"), ("hosp_cap", "hosp_cap"), ("t", "t")):
+                    got = states[b][f]
+                    exp = np.array([getattr(x, g) for x in want])
+                    assert np.array_equal(got, exp), (n, sparse, step, b, f)
+                assert np.array_equal(rewards[b], o_r), (n, sparse, step, b)
+                assert np.array_equal(ms[b], o_ms) and np.array_equal(mi[b], o_mi), (n, sparse, step, b)
+        w.close(); ow.close()
+        cases += 1
+        print("ok n=%d %s batch=%d steps=%d seed_idx=%d" % (n, "csr" if sparse else "dense", batch, steps, seed_idx), flush=True)
+    print("soak_world: %d cases, all equal" % cases)
+
+
+if __name__ == "__main__":
+    main()
