@@ -13,6 +13,8 @@
  *     retained after the call returns, except where a handle documents otherwise
  *   - every function returns an epi_status (0 = ok); epi_last_error() gives the
  *     message of the calling thread's last failure
+ *   - a handle (epi_grid, epi_world, epi_agents) serves one caller at a time: calls on the same handle from
+ *     several threads must be serialised by the caller; different handles are independent
  *   - all compute runs on the GPU; there is no CPU fallback.  When no HIP device
  *     is usable the functions return EPI_ERR_DEVICE
  *   - invariant violations that make the reference throw
