@@ -49,6 +49,20 @@ def measured_traffic(workload):
     return d.get("traffic_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
 
 
+def host_cores():
+    """Host cores the cpu_baseline leg may use: the cores this process is allowed on, capped by the share the
+    machine's scheduler hands a job (OMP_NUM_THREADS on a shared GPU box, where os.cpu_count() shows every core of
+    the machine, not the job's share)."""
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    cap = os.environ.get("OMP_NUM_THREADS", "")
+    if cap.isdigit() and int(cap) > 0:
+        allowed = min(allowed, int(cap))
+    return max(1, allowed)
+
+
 def cpu_baseline(wl, base, threads, seconds_target=15.0):
     """Oracle timed on a bounded sample: `threads` grid points (one per thread), the first `steps`
     steps of each, sized from a short probe so the leg takes about seconds_target."""
@@ -94,6 +108,8 @@ def cpu_baseline(wl, base, threads, seconds_target=15.0):
     total = sum(r[0] for r in res)
     points = sum(r[2] for r in res)
     return {"value": total / wall, "unit": "country-steps/s", "cores": threads, "kind": "port",
+            "host_cpu_count": os.cpu_count(), "cores_note": "cores = threads used = min(cores this process may run on, "
+            "OMP_NUM_THREADS); host_cpu_count = os.cpu_count() of the whole machine",
             "sample": "%d grid points x first %d of %d steps on %d threads (one point at a time per thread), %.1f s wall; "
                       "single-thread probe %.0f country-steps/s" % (points, steps, wl["steps"], threads, wall,
                                                                      probe[0][0] / probe[0][1])}
@@ -271,6 +287,67 @@ def run_learn(args, rank, local_rank, world, use_dist):
         dist.destroy_process_group()
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n_ranks, argv):
+    """Starts `n_ranks` copies of this script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, exactly what torch.distributed.run would set), waits for all of them and returns the largest
+    exit status.  The parent never touches the GPU: the children are plain child processes, not an exec of a
+    process that holds a device."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    worst = 0
+    for p in procs:
+        rc = p.wait()
+        worst = max(worst, abs(rc))
+    return worst
+
+
+def run_rehearsal(args, rank, world):
+    """--rehearse-cpu: the launcher, the process group (gloo), the interleaved split, the all-gather of the loss
+    pieces and the first-minimum scan, with NO engine behind them (the engine needs a GPU): every rank fills its
+    share with a fixed function of the grid index.  A test of the multi-rank plumbing, not a benchmark line."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from epidemicsimulator_amd.dist import first_min, gather_surface_strided, strided_bounds
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if dist.get_world_size() != args.gpus:
+        raise SystemExit("bench.py: process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
+    G = 4096
+    surface = ((np.arange(G, dtype=np.float64) * 37.0 + 55.0) % 101.0) + 1.0   # repeated minima: "first" matters
+    g0, stride, cnt, per = strided_bounds(G, world, rank)
+    local = torch.full((per,), -1.0, dtype=torch.float64)
+    local[:cnt] = torch.from_numpy(surface[g0::stride].copy())
+    full = gather_surface_strided(local, G, world, force=True)
+    idx, best = first_min(full)
+    ok = bool(np.array_equal(full, surface))
+    counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([cnt], dtype=torch.int64))
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "backend": "gloo", "n_gpus": dist.get_world_size(), "grid_points": G,
+                          "points_per_rank": [int(c.item()) for c in counts], "surface_ok": ok,
+                          "best_idx": int(idx), "best_loss": float(best)}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,18 +355,45 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the cpu_baseline leg; 0 = the host cores this process may use")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="multi-rank plumbing only, over gloo, no engine (see run_rehearsal)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+
+    # ---- N ranks, one per GPU.  Launched by torch.distributed.run the environment already names this process's
+    # rank; launched plainly with --gpus N > 1 this process only starts the N ranks and waits for them.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if not args.rehearse_cpu:
+            import torch   # device_count() does not initialise the GPU in this process
+            seen = torch.cuda.device_count()
+            if seen < args.gpus:
+                raise SystemExit("bench.py: --gpus %d needs %d HIP devices, %d visible on this machine: refusing to "
+                                 "run fewer ranks than asked for" % (args.gpus, args.gpus, seen))
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: launched with WORLD_SIZE=%d but --gpus %d: the two must agree (one rank per GPU)"
+                         % (world, args.gpus))
+    if args.rehearse_cpu:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        return run_rehearsal(args, rank, world)
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d wants device %d but only %d are visible" % (rank, local_rank,
+                                                                                         torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     # EPI_BENCH_FORCE_DIST=1 runs the RCCL exchange even with a single rank (rehearsal on a 1-GPU box)
     use_dist = world > 1 or os.environ.get("EPI_BENCH_FORCE_DIST") == "1"
@@ -297,6 +401,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
+        world = dist.get_world_size()
+    if args.cpu_threads <= 0:
+        args.cpu_threads = host_cores()
 
     if args.workload.lower() == "c5":
         return run_c5(args, rank, local_rank, world, use_dist)
@@ -349,9 +458,14 @@ def main():
     eng.set_timing(False)
 
     tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    per_rank = torch.tensor([k_ms / max(1, args.steps), float(cnt)], dtype=torch.float64, device="cuda")
+    per_rank_all = per_rank.unsqueeze(0)
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        per_rank_all = torch.empty(world, 2, dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(per_rank_all, per_rank)
     elapsed = float(tt.item())
+    per_rank_all = per_rank_all.cpu().tolist()
 
     total_cs = float(G) * n * T * args.steps
     value = total_cs / elapsed
@@ -367,7 +481,10 @@ def main():
             wl["name"], n, nb, nt, T, "CSR graph" if isinstance(wl["conn"], tuple) else "dense graph"),
             "grid_points": G, "country_steps_per_step": G * n * T,
             "parallelism": "interleaved shares of %d grid points per GPU + RCCL all-gather of the fp64 loss surface" % per if world > 1
-            else "single GPU", "best_idx": int(best[0]), "best_loss": float(best[1])},
+            else "single GPU", "best_idx": int(best[0]), "best_loss": float(best[1]),
+            "rccl_ranks": dist.get_world_size() if use_dist else 0,
+            "kernel_ms_per_step_by_rank": [round(r[0], 3) for r in per_rank_all],
+            "grid_points_by_rank": [int(r[1]) for r in per_rank_all]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": ("%s: per-launch (FETCH_SIZE*2 + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes "

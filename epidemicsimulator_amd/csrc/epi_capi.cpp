@@ -788,6 +788,16 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
             for (int c = 0; c < n; ++c) ha[(size_t)t * npad + c] = (int8_t)(act == kGreedyAction ? 0 : act);
         }
         HIP_TRY(G->actions.upload(ha));
+        // WorldToy.stepOne lets every agent learn once gStep >= learnEvery and its replay buffer holds 4 * batchSize
+        // transitions (WorldToy.scala:150-167; one transition per step, :99).  The sweep runs untrained networks
+        // only: an argmax-Q step at or after that point would consult weights this engine has not trained.
+        const long long learn_from = std::max<long long>(1, std::max<long long>(hp.learn_every, 4LL * hp.batch_size));
+        for (int gs : G->greedy_steps)
+            if (gs >= learn_from)
+                return fail(EPI_ERR_UNSUPPORTED,
+                            "grid: the agents start learning after step %lld (learnEvery %d, batchSize %d) and step %d takes argmax Q: "
+                            "rollouts that consult trained weights are not part of the sweep engine",
+                            learn_from, hp.learn_every, hp.batch_size, gs);
     }
     if (!G->greedy_steps.empty()) {
         std::vector<double> w1, w2, w3;

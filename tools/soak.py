@@ -15,9 +15,9 @@ from oracle import oracle_lib as O
 from tests import util
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+def run(budget=120.0, seed=2024, verbose=True):
+    """Runs random cases for `budget` seconds; returns the number of cases (every one compared with ==)."""
+    rng = np.random.default_rng(seed)
     O.build()
     t0 = time.time()
     cases = 0
@@ -65,8 +65,15 @@ def main():
                               [util.prof_dict(p) for p in wl["profiles"]], steps, wl["betas"], wl["travel"], ta, ha, tp, ha, het, hp=ohp)
         util.assert_grid_equal(got, want)
         cases += 1
-        print("ok n=%d %s steps=%d seed_idx=%d eps=%.1f het=%d" % (n, "csr" if sparse else "dense", steps, wl["seed_idx"], eps, het), flush=True)
-    print("soak: %d cases, all equal" % cases)
+        if verbose:
+            print("ok n=%d %s steps=%d seed_idx=%d eps=%.1f het=%d" % (n, "csr" if sparse else "dense", steps, wl["seed_idx"], eps, het), flush=True)
+    if verbose:
+        print("soak: %d cases, all equal" % cases)
+    return cases
+
+
+def main():
+    run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 
 
 if __name__ == "__main__":

@@ -21,9 +21,9 @@ def state(rng, t):
             float(rng.integers(0, 100_000)), int(t), int(rng.integers(1, 400)), 1)
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 99)
+def run(budget=120.0, seed=99, verbose=True):
+    """Runs random cases for `budget` seconds; returns the number of cases (every one compared with ==)."""
+    rng = np.random.default_rng(seed)
     O.build()
     t0 = time.time()
     cases = 0
@@ -63,8 +63,15 @@ def main():
                     assert np.array_equal(g, w), (hidden, batch, accum, cap, a, tgt)
         agents.close()
         cases += 1
-        print("ok hidden=%d batch=%d accum=%d cap=%d agents=%d" % (hidden, batch, accum, cap, n_agents), flush=True)
-    print("soak_learn: %d cases, all equal" % cases)
+        if verbose:
+            print("ok hidden=%d batch=%d accum=%d cap=%d agents=%d" % (hidden, batch, accum, cap, n_agents), flush=True)
+    if verbose:
+        print("soak_learn: %d cases, all equal" % cases)
+    return cases
+
+
+def main():
+    run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 99)
 
 
 if __name__ == "__main__":

@@ -16,9 +16,9 @@ from oracle import oracle_lib as O
 from tests import util
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+def run(budget=120.0, seed=3, verbose=True):
+    """Runs random cases for `budget` seconds; returns the number of cases (every one compared with ==)."""
+    rng = np.random.default_rng(seed)
     O.build()
     t0 = time.time()
     cases = 0
@@ -68,8 +68,15 @@ def main():
                     assert np.array_equal(g, x), (cases, k, tgt)
         w.close(); ow.close()
         cases += 1
-        print("ok hidden=%d steps=%d learn calls=%d" % (hidden, steps, learned), flush=True)
-    print("soak_train: %d cases, all equal" % cases)
+        if verbose:
+            print("ok hidden=%d steps=%d learn calls=%d" % (hidden, steps, learned), flush=True)
+    if verbose:
+        print("soak_train: %d cases, all equal" % cases)
+    return cases
+
+
+def main():
+    run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 
 
 if __name__ == "__main__":

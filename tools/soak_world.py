@@ -16,9 +16,9 @@ from oracle import oracle_lib as O
 from tests import util
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+def run(budget=120.0, seed=7, verbose=True):
+    """Runs random cases for `budget` seconds; returns the number of cases (every one compared with ==)."""
+    rng = np.random.default_rng(seed)
     O.build()
     t0 = time.time()
     cases = 0
@@ -64,8 +64,15 @@ def main():
                 assert np.array_equal(ms[b], o_ms) and np.array_equal(mi[b], o_mi), (n, sparse, step, b)
         w.close(); ow.close()
         cases += 1
-        print("ok n=%d %s batch=%d steps=%d seed_idx=%d" % (n, "csr" if sparse else "dense", batch, steps, seed_idx), flush=True)
-    print("soak_world: %d cases, all equal" % cases)
+        if verbose:
+            print("ok n=%d %s batch=%d steps=%d seed_idx=%d" % (n, "csr" if sparse else "dense", batch, steps, seed_idx), flush=True)
+    if verbose:
+        print("soak_world: %d cases, all equal" % cases)
+    return cases
+
+
+def main():
+    run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 
 
 if __name__ == "__main__":
