@@ -369,7 +369,7 @@ class Agents:
                              h.target_update_every, h.batch_size * max(1, max_grad_accum)) for h in self.hps])
         h = lib().epi_agents_create(C.c_int32(self.n), arr, C.c_int32(device))
         if not h:
-            raise EpiError(_capi.EPI_ERR_BAD_ARGUMENT, _capi.last_error())
+            _capi.raise_last()
         self._h = C.c_void_p(h)
 
     def close(self):
@@ -660,10 +660,7 @@ class WorldToy:
         d.env, d.prof, d.env_seeds, d.hp, d.device = env_arr, prof_arr, ptr(seeds, C.c_int32), hp._c(), device
         h = lib().epi_world_create(C.byref(d))
         if not h:
-            msg = _capi.last_error()
-            if "requirement failed" in msg:
-                raise IllegalArgumentException(_capi.EPI_ERR_ASSERT_STATE, msg)
-            raise EpiError(_capi.EPI_ERR_BAD_ARGUMENT, msg)
+            _capi.raise_last()
         self._h = C.c_void_p(h)
         self._agents = [_AgentStream(hp) for _ in range(n)]
         self._mlp = None
@@ -904,10 +901,7 @@ class GridEngine:
         d.device = device
         h = lib().epi_grid_create(C.byref(d))
         if not h:
-            msg = _capi.last_error()
-            if "requirement failed" in msg:
-                raise IllegalArgumentException(_capi.EPI_ERR_ASSERT_STATE, msg)
-            raise EpiError(_capi.EPI_ERR_DEVICE if "HIP" in msg or "hip" in msg else _capi.EPI_ERR_BAD_ARGUMENT, msg)
+            _capi.raise_last()
         self._h = C.c_void_p(h)
 
     def close(self):

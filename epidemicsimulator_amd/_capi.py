@@ -81,7 +81,7 @@ class WorldDesc(C.Structure):
 
 # Every symbol include/epi.h declares; tests check that the library exports all of them.
 EXPORTED_SYMBOLS = [
-    "epi_version", "epi_last_error", "epi_device_count", "epi_alloc_int", "epi_alloc_int_batch",
+    "epi_version", "epi_last_error", "epi_last_status", "epi_device_count", "epi_alloc_int", "epi_alloc_int_batch",
     "epi_env_step_batch", "epi_scale_row", "epi_gravity_matrix", "epi_java_gaussians", "epi_agent_actions", "epi_mlp_init",
     "epi_mlp_greedy_batch", "epi_grid_create", "epi_grid_run", "epi_grid_run_strided", "epi_grid_status", "epi_grid_destroy",
     "epi_grid_argmin", "epi_calibrate_grid", "epi_grid_set_timing", "epi_grid_kernel_time", "epi_world_create", "epi_world_step", "epi_world_step_greedy",
@@ -144,6 +144,12 @@ def last_error():
     buf = C.create_string_buffer(1024)
     lib().epi_last_error(buf, 1024)
     return buf.value.decode("utf-8", "replace")
+
+
+def raise_last(default=EPI_ERR_BAD_ARGUMENT):
+    """Raises the calling thread's last failure (after a *_create returned NULL)."""
+    status = lib().epi_last_status() or default
+    check(status)
 
 
 def check(status):

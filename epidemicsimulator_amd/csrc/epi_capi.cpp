@@ -491,6 +491,8 @@ EPI_API int32_t epi_last_error(char* buf, size_t cap) {
     return (int32_t)g_last_error.size();
 }
 
+EPI_API int32_t epi_last_status(void) { return g_last_code; }
+
 EPI_API int32_t epi_device_count(void) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess) return 0;

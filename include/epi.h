@@ -71,6 +71,8 @@ typedef struct epi_hyper {
 int32_t epi_version(void);
 /* Copies the calling thread's last error message (NUL-terminated) and returns its length. */
 int32_t epi_last_error(char *buf, size_t cap);
+/* The epi_status of the calling thread's last failure (what a *_create that returned NULL failed with). */
+int32_t epi_last_status(void);
 /* Number of usable HIP devices (0 when none). */
 int32_t epi_device_count(void);
 

@@ -59,3 +59,69 @@ def assert_grid_equal(got, want, rtol=1e-12):
     np.testing.assert_allclose(got["loss"], want["loss"], rtol=rtol, atol=0.0)
     assert got["best_idx"] == want["best_idx"]
     assert abs(got["best_loss"] - want["best_loss"]) <= rtol * abs(want["best_loss"])
+
+
+# ------------------------------------------------------------------------------------------------
+# Device memory for tests that hand device pointers to the C ABI.  It comes from the HIP runtime the engine
+# library itself is linked against (found among this process's mapped files once the library is loaded): a second
+# runtime in the same process -- torch bundles its own -- would not see the device.
+# ------------------------------------------------------------------------------------------------
+_hip = None
+
+
+def hip_runtime():
+    global _hip
+    if _hip is None:
+        import ctypes as C
+        from epidemicsimulator_amd import lib
+        lib()
+        path = None
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64.so" in line:
+                    path = line.split()[-1]
+                    break
+        assert path, "libepi.so is loaded but no libamdhip64.so is mapped"
+        H = C.CDLL(path)
+        H.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        H.hipFree.argtypes = [C.c_void_p]
+        H.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        H.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        _hip = H
+    return _hip
+
+
+class DeviceArray:
+    """A device allocation with the shape and dtype of a numpy array."""
+
+    def __init__(self, shape, dtype, fill=None):
+        import ctypes as C
+        self.shape, self.dtype = tuple(np.atleast_1d(shape)), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        assert hip_runtime().hipMalloc(C.byref(p), max(self.nbytes, 16)) == 0
+        self.ptr = p.value
+        if fill is not None:
+            self.upload(np.full(self.shape, fill, dtype=self.dtype))
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.nbytes == self.nbytes
+        assert hip_runtime().hipMemcpy(self.ptr, a.ctypes.data, self.nbytes, 1) == 0   # hipMemcpyHostToDevice
+
+    def download(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        assert hip_runtime().hipDeviceSynchronize() == 0
+        assert hip_runtime().hipMemcpy(out.ctypes.data, self.ptr, self.nbytes, 2) == 0   # hipMemcpyDeviceToHost
+        return out
+
+    def free(self):
+        if self.ptr:
+            hip_runtime().hipFree(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
