@@ -940,6 +940,13 @@ class GridEngine:
         check(lib().epi_grid_run_strided(self._h, g_begin, g_stride, g_count, loss_dev_ptr or None, arrival_dev_ptr or None,
                                          peak_dev_ptr or None, 1, stream or None))
 
+    def enqueue_noalloc(self, g_begin: int, g_count: int, loss_dev_ptr: int, stream: int = 0, arrival_dev_ptr: int = 0,
+                        peak_dev_ptr: int = 0, g_stride: int = 1):
+        """enqueue() through epi_grid_run_noalloc: per-episode state in the library's fixed work area, no
+        allocation of any kind; limited to what that area holds (see include/epi.h)."""
+        check(lib().epi_grid_run_noalloc(self._h, g_begin, g_stride, g_count, loss_dev_ptr or None, arrival_dev_ptr or None,
+                                         peak_dev_ptr or None, stream or None))
+
     def status(self):
         check(lib().epi_grid_status(self._h))
 

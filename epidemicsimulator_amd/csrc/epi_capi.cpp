@@ -12,6 +12,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -354,6 +355,72 @@ struct EpisodeBuffers {
     }
 };
 
+// Raw addresses of one set of per-episode work buffers: the handle's own allocations (EpisodeBuffers) or a
+// carve-up of the fixed scratch array below.
+struct WorkPtrs {
+    int32_t* st = nullptr; double* cap = nullptr; int32_t* tcur = nullptr; int32_t* arrival = nullptr;
+    int32_t* peak = nullptr; int32_t* err = nullptr; int8_t* act_ep = nullptr; int32_t* exports = nullptr;
+};
+
+WorkPtrs work_ptrs(const EpisodeBuffers& w) {
+    WorkPtrs p;
+    p.st = w.st.as<int32_t>(); p.cap = w.cap.as<double>(); p.tcur = w.tcur.as<int32_t>();
+    p.arrival = w.arrival.as<int32_t>(); p.peak = w.peak.as<int32_t>(); p.err = w.err.as<int32_t>();
+    p.act_ep = w.act_ep.as<int8_t>(); p.exports = w.exports.as<int32_t>();
+    return p;
+}
+
+// ---- fixed work area of epi_grid_run_noalloc -----------------------------------------------------------------
+// Device memory that exists from the moment the library is loaded until the process ends, one copy per GPU.
+// On the host `g_noalloc_scratch` is only a handle for hipGetSymbolAddress; the device address is looked up once
+// per device (scratch_base) and that address is what kernels and copies receive.
+constexpr size_t kNoallocScratchBytes = (size_t)32 << 20;
+constexpr int kMaxScratchDevices = 64;
+static __device__ __align__(256) unsigned char g_noalloc_scratch[kNoallocScratchBytes];
+static void* g_scratch_dev[kMaxScratchDevices];   // per-device address of the array, null until looked up
+static std::mutex g_scratch_mu;
+
+// Address of the calling thread's current device's copy of the scratch array.
+int32_t scratch_base(int device, unsigned char** out) {
+    if (device < 0 || device >= kMaxScratchDevices)
+        return fail(EPI_ERR_UNSUPPORTED, "device %d: the fixed work area is kept for devices 0..%d", device, kMaxScratchDevices - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_dev[device]) {
+        void* p = nullptr;
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch)));
+        if (!p) return fail(EPI_ERR_DEVICE, "hipGetSymbolAddress returned a null address for the fixed work area");
+        g_scratch_dev[device] = p;
+    }
+    *out = static_cast<unsigned char*>(g_scratch_dev[device]);
+    return EPI_OK;
+}
+
+// Bytes of work area `count` episodes of `npad` padded countries need, every section rounded up to 256 bytes.
+size_t scratch_need(size_t count, size_t npad, bool sparse) {
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t cells = count * npad;
+    size_t need = up(cells * 8) + up(cells * 20) + 3 * up(cells * 4) + up(count * 16) + up(cells);
+    if (sparse) need += up(cells * 16);
+    return need;
+}
+
+WorkPtrs carve_scratch(unsigned char* base, size_t count, size_t npad, bool sparse) {
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t cells = count * npad;
+    WorkPtrs p;
+    unsigned char* q = base;
+    p.cap = reinterpret_cast<double*>(q); q += up(cells * 8);
+    p.st = reinterpret_cast<int32_t*>(q); q += up(cells * 20);
+    p.tcur = reinterpret_cast<int32_t*>(q); q += up(cells * 4);
+    p.arrival = reinterpret_cast<int32_t*>(q); q += up(cells * 4);
+    p.peak = reinterpret_cast<int32_t*>(q); q += up(cells * 4);
+    p.err = reinterpret_cast<int32_t*>(q); q += up(count * 16);
+    p.act_ep = reinterpret_cast<int8_t*>(q); q += up(cells);
+    if (sparse) { p.exports = reinterpret_cast<int32_t*>(q); q += up(cells * 16); }
+    return p;
+}
+
 struct MlpDevice {
     int hidden = 0;
     double clip_q = 10.0;
@@ -396,9 +463,9 @@ const char* status_text(int code) {
 }
 
 // First failing episode of a run, from the device error table.
-int32_t collect_errors(const DevBuf& err, int count, int g_begin, int g_stride = 1) {
+int32_t collect_errors(const int32_t* err, int count, int g_begin, int g_stride = 1) {
     std::vector<int32_t> h((size_t)count * 4);
-    HIP_TRY(hipMemcpy(h.data(), err.p, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h.data(), err, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (int e = 0; e < count; ++e)
         if (h[(size_t)e * 4] != 0)
             return fail(h[(size_t)e * 4], "%s (instance %d, country %d, t=%d)", status_text(h[(size_t)e * 4]), g_begin + e * g_stride,
@@ -440,6 +507,7 @@ struct epi_grid {
     EpisodeBuffers work;
     DevBuf loss_tmp, arrival_tmp, peak_tmp;
     int last_count = 0, last_g_begin = 0, last_g_stride = 1;
+    const int32_t* last_err = nullptr;  // error table of the last enqueued run (the handle's or the fixed work area's)
     bool pending = false;
     // optional timing of the episode kernel launches (HIP events on the launch stream)
     bool timing = false;
@@ -917,7 +985,7 @@ EPI_API int32_t epi_grid_status(epi_grid* g) {
     HIP_TRY(hipDeviceSynchronize());
     if (!g->pending) return EPI_OK;
     g->pending = false;
-    return collect_errors(g->work.err, g->last_count, g->last_g_begin, g->last_g_stride);
+    return collect_errors(g->last_err, g->last_count, g->last_g_begin, g->last_g_stride);
 }
 
 EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, double* loss, int32_t* arrival, double* peak,
@@ -925,36 +993,19 @@ EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, doub
     return epi_grid_run_strided(g, g_begin, 1, g_count, loss, arrival, peak, out_on_device, stream);
 }
 
-EPI_API int32_t epi_grid_run_strided(epi_grid* g, int32_t g_begin, int32_t g_stride, int32_t g_count, double* loss,
-                                     int32_t* arrival, double* peak, int32_t out_on_device, void* stream) {
-    if (!g) return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_run: null handle");
-    const int G = g->n_beta * g->n_travel;
-    if (g_begin < 0 || g_count < 0 || g_stride < 1 || (g_count > 0 && (int64_t)g_begin + (int64_t)(g_count - 1) * g_stride >= G))
-        return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_run: points %d + k*%d, k < %d, leave the %d grid points", g_begin, g_stride, g_count, G);
-    if (g_count == 0) return EPI_OK;
-    HIP_TRY(hipSetDevice(g->device));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    int32_t rc = g->work.ensure(g_count, g->npad, g->graph.sparse);
-    if (rc) return rc;
+// Enqueues init -> episode segments (split around the argmax-Q steps) -> loss for the given grid points on `s`,
+// with the per-episode state in `wp`.  Allocates nothing unless `timed` (HIP events) or EPI_STATS asks for it.
+static int32_t grid_enqueue(epi_grid* g, int32_t g_begin, int32_t g_stride, int32_t g_count, const WorkPtrs& wp, double* d_loss,
+                            int32_t* d_arr, double* d_pk, hipStream_t s, bool may_allocate) {
     const int n = g->n, npad = g->npad;
-
-    double* d_loss = loss;
-    int32_t* d_arr = arrival;
-    double* d_pk = peak;
-    if (!out_on_device) {
-        HIP_TRY(g->loss_tmp.ensure(sizeof(double) * (size_t)g_count));
-        d_loss = g->loss_tmp.as<double>();
-        if (arrival) { HIP_TRY(g->arrival_tmp.ensure(sizeof(int32_t) * (size_t)g_count * n)); d_arr = g->arrival_tmp.as<int32_t>(); }
-        if (peak) { HIP_TRY(g->peak_tmp.ensure(sizeof(double) * (size_t)g_count * n)); d_pk = g->peak_tmp.as<double>(); }
-    }
-
+    int32_t rc;
     InitArgs ia{};
     ia.n = n; ia.npad = npad; ia.count = g_count; ia.seed_idx = g->seed_idx;
     ia.pop = g->graph.pop.as<int32_t>();
     ia.base_cap = g->base.hosp_cap;
     ia.r0 = (int32_t)g->base.r; ia.d0 = (int32_t)g->base.d; ia.v0 = (int32_t)g->base.v; ia.t0 = g->base.t;
-    ia.st = g->work.st.as<int32_t>(); ia.cap = g->work.cap.as<double>(); ia.tcur = g->work.tcur.as<int32_t>();
-    ia.arrival = g->work.arrival.as<int32_t>(); ia.peak = g->work.peak.as<int32_t>(); ia.err = g->work.err.as<int32_t>();
+    ia.st = wp.st; ia.cap = wp.cap; ia.tcur = wp.tcur;
+    ia.arrival = wp.arrival; ia.peak = wp.peak; ia.err = wp.err;
     HIP_TRY(launch_init(ia, s));
 
     EpisodeArgs ea{};
@@ -967,7 +1018,7 @@ EPI_API int32_t epi_grid_run_strided(epi_grid* g, int32_t g_begin, int32_t g_str
     if (g->graph.sparse) {
         ea.qval_seed = g->qseed.as<double>(); ea.seed_deg = g->seed_deg; ea.seed_long = g->seed_long;
         ea.seed_block = g->seed_block;
-        ea.exports = g->work.exports.as<int32_t>();
+        ea.exports = wp.exports;
     } else {
         ea.qseed = g->qseed.as<double>(); ea.qtop_seed = g->qtop_seed.as<double>();
     }
@@ -976,19 +1027,24 @@ EPI_API int32_t epi_grid_run_strided(epi_grid* g, int32_t g_begin, int32_t g_str
     ea.actions = g->actions.as<int8_t>(); ea.act_t0 = 0;
     ea.noise = g->noise.as<double>(); ea.noise_t0 = 0;
     ea.st = ia.st; ea.cap = ia.cap; ea.tcur = ia.tcur; ea.arrival = ia.arrival; ea.peak = ia.peak; ea.err = ia.err;
-    if (getenv("EPI_STATS")) {
+    if (may_allocate && getenv("EPI_STATS")) {
         if (!g->stats.p) {
             HIP_TRY(g->stats.ensure(64 * sizeof(unsigned long long)));
             HIP_TRY(hipMemset(g->stats.p, 0, 64 * sizeof(unsigned long long)));
         }
         ea.stats = g->stats.as<unsigned long long>();
     }
+    auto episode = [&](const EpisodeArgs& e) -> int32_t {
+        if (may_allocate) return timed_episode(g, e, s);
+        HIP_TRY(launch_episode(e, s));
+        return EPI_OK;
+    };
 
     int t0 = 0;
     for (int gs : g->greedy_steps) {
         if (gs > t0) {
             ea.t_begin = t0; ea.t_end = gs; ea.act_episode = nullptr;
-            rc = timed_episode(g, ea, s);
+            rc = episode(ea);
             if (rc) return rc;
         }
         MlpArgs ma{};
@@ -996,16 +1052,16 @@ EPI_API int32_t epi_grid_run_strided(epi_grid* g, int32_t g_begin, int32_t g_str
         ma.state_t_max = g->base.t_max;
         ma.st = ia.st; ma.cap = ia.cap; ma.tcur = ia.tcur; ma.plane = (size_t)g_count * npad;
         g->mlp.fill(ma);
-        ma.act_episode = g->work.act_ep.as<int8_t>();
+        ma.act_episode = wp.act_ep;
         HIP_TRY(launch_mlp(ma, s));
         ea.t_begin = gs; ea.t_end = gs + 1; ea.act_episode = ma.act_episode;
-        rc = timed_episode(g, ea, s);
+        rc = episode(ea);
         if (rc) return rc;
         t0 = gs + 1;
     }
     if (t0 < g->steps) {
         ea.t_begin = t0; ea.t_end = g->steps; ea.act_episode = nullptr;
-        rc = timed_episode(g, ea, s);
+        rc = episode(ea);
         if (rc) return rc;
     }
 
@@ -1021,6 +1077,40 @@ EPI_API int32_t epi_grid_run_strided(epi_grid* g, int32_t g_begin, int32_t g_str
     g->last_count = g_count;
     g->last_g_begin = g_begin;
     g->last_g_stride = g_stride;
+    g->last_err = wp.err;
+    return EPI_OK;
+}
+
+static int32_t grid_check_points(const epi_grid* g, int32_t g_begin, int32_t g_stride, int32_t g_count, const char* who) {
+    const int G = g->n_beta * g->n_travel;
+    if (g_begin < 0 || g_count < 0 || g_stride < 1 || (g_count > 0 && (int64_t)g_begin + (int64_t)(g_count - 1) * g_stride >= G))
+        return fail(EPI_ERR_BAD_ARGUMENT, "%s: points %d + k*%d, k < %d, leave the %d grid points", who, g_begin, g_stride, g_count, G);
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_grid_run_strided(epi_grid* g, int32_t g_begin, int32_t g_stride, int32_t g_count, double* loss,
+                                     int32_t* arrival, double* peak, int32_t out_on_device, void* stream) {
+    if (!g) return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_run: null handle");
+    int32_t rc = grid_check_points(g, g_begin, g_stride, g_count, "epi_grid_run");
+    if (rc) return rc;
+    if (g_count == 0) return EPI_OK;
+    HIP_TRY(hipSetDevice(g->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = g->work.ensure(g_count, g->npad, g->graph.sparse);
+    if (rc) return rc;
+    const int n = g->n;
+
+    double* d_loss = loss;
+    int32_t* d_arr = arrival;
+    double* d_pk = peak;
+    if (!out_on_device) {
+        HIP_TRY(g->loss_tmp.ensure(sizeof(double) * (size_t)g_count));
+        d_loss = g->loss_tmp.as<double>();
+        if (arrival) { HIP_TRY(g->arrival_tmp.ensure(sizeof(int32_t) * (size_t)g_count * n)); d_arr = g->arrival_tmp.as<int32_t>(); }
+        if (peak) { HIP_TRY(g->peak_tmp.ensure(sizeof(double) * (size_t)g_count * n)); d_pk = g->peak_tmp.as<double>(); }
+    }
+    rc = grid_enqueue(g, g_begin, g_stride, g_count, work_ptrs(g->work), d_loss, d_arr, d_pk, s, true);
+    if (rc) return rc;
     if (out_on_device) return EPI_OK;
 
     HIP_TRY(hipStreamSynchronize(s));
@@ -1028,6 +1118,33 @@ EPI_API int32_t epi_grid_run_strided(epi_grid* g, int32_t g_begin, int32_t g_str
     if (arrival) HIP_TRY(hipMemcpy(arrival, d_arr, sizeof(int32_t) * (size_t)g_count * n, hipMemcpyDeviceToHost));
     if (peak) HIP_TRY(hipMemcpy(peak, d_pk, sizeof(double) * (size_t)g_count * n, hipMemcpyDeviceToHost));
     return epi_grid_status(g);
+}
+
+// The sweep of epi_grid_run_strided(out_on_device = 1) without any allocation: the per-episode state (compartments,
+// hospCap, clocks, arrival / peak, error table, argmax-Q actions, sparse export lists) lives in the fixed work area
+// g_noalloc_scratch instead of buffers the handle allocates on demand.  Every call on a GPU shares that GPU's array
+// and overwrites it from the start (the init kernel writes every word the episode kernels read), so two calls that
+// overlap in time on one GPU -- different streams, threads or handles -- race; calls on one stream are ordered.
+EPI_API int32_t epi_grid_run_noalloc(epi_grid* g, int32_t g_begin, int32_t g_stride, int32_t g_count, double* loss_dev,
+                                     int32_t* arrival_dev, double* peak_dev, void* stream) {
+    if (!g) return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_run_noalloc: null handle");
+    int32_t rc = grid_check_points(g, g_begin, g_stride, g_count, "epi_grid_run_noalloc");
+    if (rc) return rc;
+    if (g_count == 0) return EPI_OK;
+    if (!loss_dev) return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_run_noalloc: loss_dev must be device memory for %d doubles", g_count);
+    const size_t need = scratch_need((size_t)g_count, (size_t)g->npad, g->graph.sparse);
+    if (need > kNoallocScratchBytes)
+        return fail(EPI_ERR_UNSUPPORTED,
+                    "epi_grid_run_noalloc: %d episodes of %d padded countries need %zu bytes of work area, the fixed one holds %zu "
+                    "(at most %zu episodes of this world per call): split the call or use epi_grid_run_strided",
+                    g_count, g->npad, need, kNoallocScratchBytes,
+                    (size_t)(kNoallocScratchBytes / (scratch_need(1, (size_t)g->npad, g->graph.sparse) + 1)));
+    unsigned char* base = nullptr;
+    rc = scratch_base(g->device, &base);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(g->device));
+    const WorkPtrs wp = carve_scratch(base, (size_t)g_count, (size_t)g->npad, g->graph.sparse);
+    return grid_enqueue(g, g_begin, g_stride, g_count, wp, loss_dev, arrival_dev, peak_dev, static_cast<hipStream_t>(stream), false);
 }
 
 EPI_API int32_t epi_calibrate_grid(const epi_grid_desc* desc, double* loss, int32_t* arrival, double* peak, int32_t* best_idx,

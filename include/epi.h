@@ -160,6 +160,19 @@ int32_t epi_grid_run(epi_grid *g, int32_t g_begin, int32_t g_count, double *loss
  * beta row cost about the same, episodes of different rows do not. */
 int32_t epi_grid_run_strided(epi_grid *g, int32_t g_begin, int32_t g_stride, int32_t g_count, double *loss,
                              int32_t *arrival, double *peak, int32_t out_on_device, void *stream);
+/* No counterpart in the reference: for callers that cannot allocate device memory -- code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  The sweep of epi_grid_run_strided with
+ * out_on_device != 0 (same kernels, same results), but the per-episode state lives in a fixed 32 MiB device array
+ * that the library holds on every GPU it runs on until the process ends, and the call allocates and frees
+ * nothing (no hipMalloc / hipFree / events).  loss_dev[g_count] is device memory on the handle's device;
+ * arrival_dev[g_count][n] and peak_dev[g_count][n] are optional device memory.  The work is enqueued on `stream`;
+ * epi_grid_status() collects its status.  Limit: g_count episodes of the world's padded width must fit the
+ * array (41 bytes per padded country and episode plus 16 per episode, 57 for sparse graphs: up to 798 episodes
+ * of 1,000 countries, 3,192 of 200, 29 of a 20,000-patch world) -- larger requests return EPI_ERR_UNSUPPORTED
+ * and run nothing.  All calls on one GPU share the array: calls that overlap in time on one GPU race (calls on one
+ * stream are ordered and safe); it is overwritten from the start by every call. */
+int32_t epi_grid_run_noalloc(epi_grid *g, int32_t g_begin, int32_t g_stride, int32_t g_count, double *loss_dev,
+                             int32_t *arrival_dev, double *peak_dev, void *stream);
 /* Waits for the last enqueued run and returns its status (first failing grid point wins). */
 int32_t epi_grid_status(epi_grid *g);
 int32_t epi_grid_destroy(epi_grid *g);
