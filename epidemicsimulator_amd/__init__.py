@@ -17,7 +17,7 @@ from . import _capi
 from ._capi import (EpiError, IllegalArgumentException, EPI_OK, check, f64, i32, lib, ptr)
 
 __all__ = ["Action", "State", "HyperParams", "TrainConfig", "Geo", "ToyConn", "EpidemicEnv", "WorldToy",
-           "Calibrate", "Validation", "GridEngine", "Snapshots", "EpiError", "IllegalArgumentException"]
+           "Calibrate", "Validation", "GridEngine", "MultiGridEngine", "Snapshots", "EpiError", "IllegalArgumentException"]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -872,6 +872,31 @@ class WorldToy:
 # ------------------------------------------------------------------------------------------------
 # Calibrate.scala
 # ------------------------------------------------------------------------------------------------
+def _grid_desc(hp, steps, base, seed_idx, pops, conn, profiles, betas, travel, t_arrive, t_peak, heterogeneous, device):
+    """Fills an epi_grid_desc; returns it with the arrays it points into (keep them alive while it is used)."""
+    n = len(pops)
+    pops = i32(pops)
+    dense, rp, col, val = _csr_or_dense(conn)
+    prof_arr = (_capi.Profile * n)(*[p._c() if hasattr(p, "_c") else _capi.Profile(*p) for p in profiles])
+    ta = np.zeros(n); tp = np.zeros(n)
+    ha = np.zeros(n, dtype=np.uint8); hk = np.zeros(n, dtype=np.uint8)
+    for c, v in (t_arrive or {}).items():
+        ta[c], ha[c] = v, 1
+    for c, v in (t_peak or {}).items():
+        tp[c], hk[c] = v, 1
+    d = _capi.GridDesc()
+    d.n, d.pop = n, ptr(pops, C.c_int32)
+    d.conn = ptr(dense, C.c_double) if dense is not None else None
+    d.csr_rowptr = ptr(rp, C.c_int32) if rp is not None else None
+    d.csr_col = ptr(col, C.c_int32) if col is not None else None
+    d.csr_val = ptr(val, C.c_double) if val is not None else None
+    d.seed_idx, d.heterogeneous, d.base, d.prof, d.hp, d.steps = seed_idx, int(heterogeneous), base._c(), prof_arr, hp._c(), steps
+    d.n_beta, d.betas, d.n_travel, d.travel = len(betas), ptr(betas, C.c_double), len(travel), ptr(travel, C.c_double)
+    d.t_arrive, d.has_arrive, d.t_peak, d.has_peak = ptr(ta, C.c_double), ptr(ha, C.c_uint8), ptr(tp, C.c_double), ptr(hk, C.c_uint8)
+    d.device = device
+    return d, (pops, dense, rp, col, val, prof_arr, ta, tp, ha, hk, betas, travel)
+
+
 class GridEngine:
     """Device-resident calibration sweep (epi_grid_*): build once, run slabs of grid points."""
 
@@ -880,25 +905,8 @@ class GridEngine:
         self.n = len(pops)
         self.betas, self.travel = f64(betas), f64(travel)
         self.G = len(self.betas) * len(self.travel)
-        pops = i32(pops)
-        dense, rp, col, val = _csr_or_dense(conn)
-        prof_arr = (_capi.Profile * self.n)(*[p._c() if hasattr(p, "_c") else _capi.Profile(*p) for p in profiles])
-        ta = np.zeros(self.n); tp = np.zeros(self.n)
-        ha = np.zeros(self.n, dtype=np.uint8); hk = np.zeros(self.n, dtype=np.uint8)
-        for c, v in (t_arrive or {}).items():
-            ta[c], ha[c] = v, 1
-        for c, v in (t_peak or {}).items():
-            tp[c], hk[c] = v, 1
-        d = _capi.GridDesc()
-        d.n, d.pop = self.n, ptr(pops, C.c_int32)
-        d.conn = ptr(dense, C.c_double) if dense is not None else None
-        d.csr_rowptr = ptr(rp, C.c_int32) if rp is not None else None
-        d.csr_col = ptr(col, C.c_int32) if col is not None else None
-        d.csr_val = ptr(val, C.c_double) if val is not None else None
-        d.seed_idx, d.heterogeneous, d.base, d.prof, d.hp, d.steps = seed_idx, int(heterogeneous), base._c(), prof_arr, hp._c(), steps
-        d.n_beta, d.betas, d.n_travel, d.travel = len(self.betas), ptr(self.betas, C.c_double), len(self.travel), ptr(self.travel, C.c_double)
-        d.t_arrive, d.has_arrive, d.t_peak, d.has_peak = ptr(ta, C.c_double), ptr(ha, C.c_uint8), ptr(tp, C.c_double), ptr(hk, C.c_uint8)
-        d.device = device
+        d, _keep = _grid_desc(hp, steps, base, seed_idx, pops, conn, profiles, self.betas, self.travel, t_arrive, t_peak,
+                              heterogeneous, device)
         h = lib().epi_grid_create(C.byref(d))
         if not h:
             _capi.raise_last()
@@ -960,6 +968,50 @@ class GridEngine:
         return ms.value, k.value, cs.value
 
 
+class MultiGridEngine:
+    """The sweep over several GPUs from one process (epi_grid_multi_*): share k of the interleaved split runs on
+    devices[k]; the loss pieces are all-gathered with RCCL; run() returns the whole surface and its first minimum."""
+
+    def __init__(self, hp: HyperParams, steps: int, base: State, seed_idx: int, pops, conn, profiles, betas, travel,
+                 t_arrive=None, t_peak=None, heterogeneous=True, devices: Sequence[int] = (0,)):
+        self.n = len(pops)
+        self.betas, self.travel = f64(betas), f64(travel)
+        self.G = len(self.betas) * len(self.travel)
+        d, _keep = _grid_desc(hp, steps, base, seed_idx, pops, conn, profiles, self.betas, self.travel, t_arrive, t_peak,
+                              heterogeneous, 0)
+        dev = i32(list(devices))
+        h = lib().epi_grid_multi_create(C.byref(d), ptr(dev, C.c_int32), C.c_int32(len(dev)))
+        if not h:
+            _capi.raise_last(_capi.EPI_ERR_DEVICE)
+        self._h = C.c_void_p(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().epi_grid_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ranks(self) -> Tuple[int, int]:
+        """(communicator ranks = distinct devices, share slots per rank)."""
+        r = C.c_int32(0); sl = C.c_int32(0)
+        check(lib().epi_grid_multi_ranks(self._h, C.byref(r), C.byref(sl)))
+        return r.value, sl.value
+
+    def run(self, want_metrics: bool = True):
+        loss = np.zeros(max(self.G, 1))
+        arr = np.zeros((self.G, self.n), dtype=np.int32) if want_metrics else None
+        pk = np.zeros((self.G, self.n)) if want_metrics else None
+        bi = C.c_int32(0); bl = C.c_double(0)
+        check(lib().epi_grid_multi_run(self._h, loss.ctypes.data, arr.ctypes.data if want_metrics else None,
+                                       pk.ctypes.data if want_metrics else None, C.byref(bi), C.byref(bl)))
+        return dict(loss=loss[:self.G], arrival=arr, peak=pk, best_idx=bi.value, best_loss=bl.value)
+
+
 def grid_argmin(loss) -> Tuple[int, float]:
     loss = f64(loss)
     bi = C.c_int32(0); bl = C.c_double(0)
@@ -978,7 +1030,7 @@ class Calibrate:
     def grid_surface(hp: HyperParams, cfg: TrainConfig, base: State, seed_idx: int, targets: "Calibrate.Targets",
                      beta_grid: Sequence[float], travel_scales: Sequence[float], validate: bool = True,
                      heterogeneous: bool = True, countries: Optional[Sequence[Geo.Country]] = None, conn=None,
-                     device: int = 0):
+                     device: int = 0, devices: Optional[Sequence[int]] = None):
         """Calibrate.gridSurface (:84-116): (rows [(beta, ts, loss)], (bestLoss, (beta, ts)))."""
         countries = list(countries) if countries is not None else list(ToyConn.C)
         conn = ToyConn.W if conn is None else conn
@@ -990,10 +1042,14 @@ class Calibrate:
         if len(beta_grid) == 0 or len(travel_scales) == 0:
             best = (beta_grid[0] if len(beta_grid) else 0.25, travel_scales[0] if len(travel_scales) else 1.0)
             return [], (1.7976931348623157e308, best)
-        eng = GridEngine(hp, cfg.steps_per_epoch, base, seed_idx, [c.pop for c in countries], conn, profiles,
-                         beta_grid, travel_scales, ta, tp, heterogeneous, device)
+        if devices is not None:   # several GPUs of the node from this process, loss pieces all-gathered with RCCL
+            eng = MultiGridEngine(hp, cfg.steps_per_epoch, base, seed_idx, [c.pop for c in countries], conn, profiles,
+                                  beta_grid, travel_scales, ta, tp, heterogeneous, devices)
+        else:
+            eng = GridEngine(hp, cfg.steps_per_epoch, base, seed_idx, [c.pop for c in countries], conn, profiles,
+                             beta_grid, travel_scales, ta, tp, heterogeneous, device)
         try:
-            out = eng.run(0, None, want_metrics=False)
+            out = eng.run(want_metrics=False)
         finally:
             eng.close()
         loss = out["loss"]

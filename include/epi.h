@@ -188,6 +188,26 @@ int32_t epi_grid_argmin(const double *loss, int32_t count, int32_t *best_idx, do
 int32_t epi_calibrate_grid(const epi_grid_desc *desc, double *loss, int32_t *arrival, double *peak,
                            int32_t *best_idx, double *best_loss);
 
+/* ---- Calibrate.gridSurface (Calibrate.scala:84-116) over several GPUs of one node, from one process ----------
+ * The grid loop (Calibrate.scala:100-113) runs independent rollouts: the flat beta-major grid is cut into n_dev
+ * interleaved shares (share k = grid points k, k + n_dev, ...), share k runs on devices[k] with an engine of its
+ * own, and the fp64 loss pieces are all-gathered with RCCL (ncclAllGather over the distinct devices, xGMI) so that
+ * every device ends up with the whole surface; the first-minimum scan of Calibrate.scala:96,112 then runs on the
+ * host.  desc->device is ignored.  A device may be named more than once (several engines on one GPU).  librccl is
+ * opened on first use; without it the create call fails with EPI_ERR_DEVICE. */
+typedef struct epi_grid_multi epi_grid_multi;
+epi_grid_multi *epi_grid_multi_create(const epi_grid_desc *desc, const int32_t *devices, int32_t n_dev);
+/* One whole sweep: loss[n_beta*n_travel] beta-major (may be NULL), optional arrival/peak [G][n], the first
+ * minimum.  Synchronous.  May be called repeatedly (tables, engines and the communicator are reused). */
+int32_t epi_grid_multi_run(epi_grid_multi *m, double *loss, int32_t *arrival, double *peak, int32_t *best_idx,
+                           double *best_loss);
+/* Communicator size (distinct devices) and the number of share slots each rank contributes to the all-gather. */
+int32_t epi_grid_multi_ranks(const epi_grid_multi *m, int32_t *n_ranks, int32_t *slots_per_rank);
+int32_t epi_grid_multi_destroy(epi_grid_multi *m);
+/* create + run + destroy. */
+int32_t epi_calibrate_grid_multi(const epi_grid_desc *desc, const int32_t *devices, int32_t n_dev, double *loss,
+                                 int32_t *arrival, double *peak, int32_t *best_idx, double *best_loss);
+
 /* ---- WorldToy (WorldToy.scala:11-235): batched worlds stepped on the device ------------------- */
 typedef struct epi_world_desc {
     int32_t n;

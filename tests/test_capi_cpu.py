@@ -135,6 +135,10 @@ def test_compute_entry_points_need_a_gpu(epi):
     with pytest.raises(epi.EpiError) as ei:
         epi.Agents([epi.HyperParams()])
     assert "HIP" in str(ei.value)
+    with pytest.raises(epi.EpiError) as ei:                # the multi-device sweep: no device, no engine, no fallback
+        epi.MultiGridEngine(epi.HyperParams(), 3, synth.base_state(3), 0, [c.pop for c in wl["countries"]], wl["conn"],
+                            wl["profiles"], wl["betas"], wl["travel"], devices=[0, 1])
+    assert ei.value.status == 2 and "HIP" in str(ei.value)
 
 
 def test_bad_arguments_are_rejected_before_the_device(epi):
