@@ -853,6 +853,45 @@ class WorldToy:
                 self.last_losses[nd.idx] = float(l)
         return [(nd.name, s, float(rv)) for nd, s, rv in zip(self.nodes, states[0], r[0])]
 
+    def rollout_greedy(self, steps: int, t_max: int, want_series: bool = True, want_states: bool = True):
+        """`steps` stepOneGreedy calls kept on the device (epi_world_rollout_greedy): every node asks its own agent's
+        network when the world learns (WorldToy.scala:177), the untrained network otherwise.  Returns a dict with
+        i_series [steps][batch][n] (optional), arrival [batch][n], peak [batch][n], states (STATE_DTYPE [batch][n])."""
+        agents = None
+        if self.learning and self._pool is not None:
+            agents = self._pool._h
+        else:
+            self._ensure_untrained_mlp()
+        B, n = self.batch, self.n
+        series = np.zeros((steps, B, n)) if want_series else None
+        arr = np.zeros((B, n), dtype=np.int32); pk = np.zeros((B, n))
+        st = np.empty((B, n), dtype=WorldToy.STATE_DTYPE) if want_states else None
+        check(lib().epi_world_rollout_greedy(self._h, agents, C.c_int32(steps), C.c_int32(t_max),
+                                             series.ctypes.data if want_series else None, arr.ctypes.data, pk.ctypes.data,
+                                             st.ctypes.data if want_states else None))
+        self._sync_nodes()
+        return dict(i_series=series, arrival=arr, peak=pk, states=st)
+
+    def evaluate_greedy(self, max_eval_steps: int = 800) -> Dict[str, float]:
+        """The periodic greedy evaluation of the trainer (MutliTrainer.scala:128-161): snapshot, reset, `max_eval_steps`
+        greedy steps on the device, metrics of the I series per country, restore."""
+        assert self.batch == 1
+        saved = self.snapshot_states()
+        self.reset_to_initial()
+        out = self.rollout_greedy(max_eval_steps, max_eval_steps, want_series=True, want_states=False)
+        metrics: Dict[str, float] = {}
+        for k, nd in enumerate(self.nodes):
+            series = out["i_series"][:, 0, k]
+            norm = series / max(1.0, float(nd.pop))
+            metrics["eval_arrival_%s" % nd.name] = float(Validation.arrival_time(series, 10.0))
+            metrics["eval_peakI_%s" % nd.name] = float(Validation.peak_i(series))
+            metrics["eval/arrivalN_%s" % nd.name] = float(Validation.arrival_time(norm, 1e-4))
+            metrics["eval/peakI_norm_%s" % nd.name] = float(Validation.peak_i(norm))
+            assert metrics["eval_arrival_%s" % nd.name] == out["arrival"][0, k]
+            assert metrics["eval_peakI_%s" % nd.name] == out["peak"][0, k]
+        self.restore_states(saved)
+        return metrics
+
     def step_one_greedy(self, t_max: int) -> List[Tuple[str, State, float]]:  # :172-235
         if self.learning and self._pool is not None:   # every node asks its own, possibly trained, network (:177)
             _, g = self._pool.q_values([nd.s for nd in self.nodes])

@@ -23,6 +23,7 @@
 
 #include "../../include/epi.h"
 #include "epi_host.hpp"
+#include "epi_kernels.hpp"
 #include "java_compat.hpp"
 
 #define EPI_API extern "C" __attribute__((visibility("default")))
@@ -35,20 +36,6 @@ constexpr int kOut = 8;       // Action.values.length
 constexpr int kXStride = 8;   // features padded to 8 doubles per row
 constexpr int kGradRows = 16; // rows of gW2 one thread accumulates (one read of h1 serves them all)
 constexpr int kMaxHidden = 256;
-
-// One network in device memory, every matrix with row stride Hp (hidden rounded up to 64):
-//   W1t[7][Hp]  b1[Hp]  W2[Hp][Hp] (row = output)  W2t[Hp][Hp] (row = input)  b2[Hp]  W3[8][Hp]  b3[8]
-struct NetLayout {
-    int H, Hp;
-    __host__ __device__ size_t w1t() const { return 0; }
-    __host__ __device__ size_t b1() const { return (size_t)kIn * Hp; }
-    __host__ __device__ size_t w2() const { return b1() + Hp; }
-    __host__ __device__ size_t w2t() const { return w2() + (size_t)Hp * Hp; }
-    __host__ __device__ size_t b2() const { return w2t() + (size_t)Hp * Hp; }
-    __host__ __device__ size_t w3() const { return b2() + Hp; }
-    __host__ __device__ size_t b3() const { return w3() + (size_t)kOut * Hp; }
-    __host__ __device__ size_t size() const { return b3() + kOut; }
-};
 
 struct AgentHyperDev {
     double gamma, lr, clip_q, grad_clip;
@@ -511,26 +498,6 @@ struct epi_agents {
 
 namespace {
 
-// Host image of one network in the device layout.
-void pack_net(const NetLayout& nl, const double* W1, const double* b1, const double* W2, const double* b2,
-              const double* W3, const double* b3, double* out) {
-    std::fill(out, out + nl.size(), 0.0);
-    const int H = nl.H, Hp = nl.Hp;
-    for (int i = 0; i < H; ++i) {
-        for (int j = 0; j < kIn; ++j) out[nl.w1t() + (size_t)j * Hp + i] = W1[(size_t)i * kIn + j];
-        out[nl.b1() + i] = b1 ? b1[i] : 0.0;
-        for (int j = 0; j < H; ++j) {
-            out[nl.w2() + (size_t)i * Hp + j] = W2[(size_t)i * H + j];
-            out[nl.w2t() + (size_t)j * Hp + i] = W2[(size_t)i * H + j];
-        }
-        out[nl.b2() + i] = b2 ? b2[i] : 0.0;
-    }
-    for (int o = 0; o < kOut; ++o) {
-        for (int j = 0; j < H; ++j) out[nl.w3() + (size_t)o * Hp + j] = W3[(size_t)o * H + j];
-        out[nl.b3() + o] = b3 ? b3[o] : 0.0;
-    }
-}
-
 int32_t check_ids(const epi_agents* g, const int32_t* ids, int32_t count) {
     if (count < 0 || count > g->n) return fail(EPI_ERR_BAD_ARGUMENT, "count %d outside [0,%d]", count, g->n);
     if (!ids) return EPI_OK;
@@ -599,6 +566,21 @@ EPI_API epi_agents* epi_agents_create(int32_t n_agents, const epi_learn_hyper* h
         return nullptr;
     return g.release();
 }
+
+// The networks of the handle for kernels of other translation units (greedy rollouts of a world whose nodes ask
+// their own agents): online network of agent k at nets + k * net_stride, its clamp at clip_ptr[k * clip_stride].
+namespace epi {
+int32_t agents_net_view(epi_agents* g, AgentsNetView* v) {
+    if (!g || !v) return fail(EPI_ERR_BAD_ARGUMENT, "agents_net_view: null argument");
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipStreamSynchronize(g->stream));   // a learn call still in flight finishes before its weights are read
+    v->device = g->device; v->n_agents = g->n; v->nl = g->nl;
+    v->nets = g->nets.as<double>(); v->net_stride = 2 * g->nl.size();
+    v->clip_ptr = reinterpret_cast<const double*>(g->hyper.as<AgentHyperDev>()) + 2;   // AgentHyperDev::clip_q
+    v->clip_stride = (int)(sizeof(AgentHyperDev) / sizeof(double));
+    return EPI_OK;
+}
+}  // namespace epi
 
 EPI_API int32_t epi_agents_destroy(epi_agents* g) {
     if (!g) return EPI_OK;

@@ -422,33 +422,28 @@ WorkPtrs carve_scratch(unsigned char* base, size_t count, size_t npad, bool spar
 }
 
 struct MlpDevice {
-    int hidden = 0;
+    NetLayout nl{0, 0};
     double clip_q = 10.0;
-    DevBuf W1, b1, W2T, b2, W3, b3;
-    bool has_bias = false;
+    DevBuf net;   // one network in NetLayout form
     int32_t upload(int h, const double* w1, const double* bb1, const double* w2, const double* bb2, const double* w3,
                    const double* bb3, double clip) {
-        if (h < 1 || h > 128) return fail(EPI_ERR_BAD_ARGUMENT, "hidden = %d: the device network supports 1..128 units", h);
-        hidden = h;
+        if (h < 1 || h > 256) return fail(EPI_ERR_UNSUPPORTED, "hidden = %d: the device network supports 1..256 units", h);
+        nl.H = h;
+        nl.Hp = (h + 63) / 64 * 64;
         clip_q = clip;
-        std::vector<double> t((size_t)h * h);
-        for (int u = 0; u < h; ++u)
-            for (int k = 0; k < h; ++k) t[(size_t)k * h + u] = w2[(size_t)u * h + k];
-        HIP_TRY(W1.upload(std::vector<double>(w1, w1 + (size_t)h * 7)));
-        HIP_TRY(W2T.upload(t));
-        HIP_TRY(W3.upload(std::vector<double>(w3, w3 + (size_t)8 * h)));
-        std::vector<double> z1((size_t)h, 0.0), z3(8, 0.0);
-        HIP_TRY(b1.upload(bb1 ? std::vector<double>(bb1, bb1 + h) : z1));
-        HIP_TRY(b2.upload(bb2 ? std::vector<double>(bb2, bb2 + h) : z1));
-        HIP_TRY(b3.upload(bb3 ? std::vector<double>(bb3, bb3 + 8) : z3));
+        std::vector<double> img(nl.size());
+        pack_net(nl, w1, bb1, w2, bb2, w3, bb3, img.data());
+        HIP_TRY(net.upload(img));
         return EPI_OK;
     }
     void fill(MlpArgs& a) const {
-        a.hidden = hidden;
-        a.W1 = W1.as<double>(); a.b1 = b1.as<double>();
-        a.W2T = W2T.as<double>(); a.b2 = b2.as<double>();
-        a.W3 = W3.as<double>(); a.b3 = b3.as<double>();
+        a.nl = nl;
+        a.nets = net.as<double>();
+        a.net_stride = 0;
+        a.per_country = 0;
         a.clip_q = clip_q;
+        a.clip_ptr = nullptr;
+        a.clip_stride = 0;
     }
 };
 
@@ -528,6 +523,7 @@ struct epi_world {
     bool mlp_set = false;
     EpisodeBuffers work;
     DevBuf act_dev, gauss_dev, reward_dev, flow_s, flow_i, q_tmp;
+    DevBuf noise_tab, series_dev, arr_out, peak_out;   // greedy rollouts: per-step noise table, I-series, compact metrics
     // compact [batch][n] images of the caller's arrays in page-locked, device-mapped host memory
     PinBuf pin_act, pin_gauss, pin_states, pin_rewards, pin_actions, pin_err;
 
@@ -699,7 +695,7 @@ EPI_API int32_t epi_mlp_greedy_batch(const epi_state* states, int32_t batch, int
     HIP_TRY(da.ensure((size_t)batch * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(ds.p, states, (size_t)batch * sizeof(epi_state), hipMemcpyHostToDevice));
     MlpArgs a{};
-    a.rows = batch; a.n = 1; a.npad = 1;
+    a.rows = batch; a.n = 1; a.npad = 1; a.count = batch;
     a.states = ds.as<epi_state>();
     m.fill(a);
     a.act_out = da.as<int32_t>();
@@ -1048,7 +1044,7 @@ static int32_t grid_enqueue(epi_grid* g, int32_t g_begin, int32_t g_stride, int3
             if (rc) return rc;
         }
         MlpArgs ma{};
-        ma.rows = g_count * n; ma.n = n; ma.npad = npad;
+        ma.rows = g_count * n; ma.n = n; ma.npad = npad; ma.count = g_count;
         ma.state_t_max = g->base.t_max;
         ma.st = ia.st; ma.cap = ia.cap; ma.tcur = ia.tcur; ma.plane = (size_t)g_count * npad;
         g->mlp.fill(ma);
@@ -1387,10 +1383,13 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
         std::memcpy(w->pin_act.p, actions, compact * sizeof(int32_t));
         io.actions = w->pin_act.on_device<int32_t>();
     }
-    HIP_TRY(launch_world_pack(io, s));
+    // Small worlds (the toy world of the batched DDQN rollout): the episode kernel reads the compact inputs and writes
+    // the compact results itself -- one launch per step instead of pack + episode + unpack.
+    const bool fused = !greedy && !w->graph.sparse && n <= 16 && npad == 64;
+    if (!fused) HIP_TRY(launch_world_pack(io, s));
     if (greedy) {
         MlpArgs ma{};
-        ma.rows = B * n; ma.n = n; ma.npad = npad;
+        ma.rows = B * n; ma.n = n; ma.npad = npad; ma.count = B;
         ma.state_t_max = w->base.t_max;
         ma.st = w->work.st.as<int32_t>(); ma.cap = w->work.cap.as<double>(); ma.tcur = w->work.tcur.as<int32_t>();
         ma.plane = cells;
@@ -1415,6 +1414,14 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
     ea.arrival = w->work.arrival.as<int32_t>(); ea.peak = w->work.peak.as<int32_t>(); ea.err = w->work.err.as<int32_t>();
     ea.rwd = w->rwd.as<RewardConsts>(); ea.reward_out = w->reward_dev.as<double>();
     ea.flow_s = w->flow_s.as<int32_t>(); ea.flow_i = w->flow_i.as<int32_t>();
+    if (fused) {
+        ea.io_actions = io.actions; ea.io_gauss = io.gauss; ea.io_gauss_row = io.gauss_row;
+        ea.io_states = out_states ? w->pin_states.on_device<epi_state>() : nullptr;
+        ea.io_rewards = out_rewards ? w->pin_rewards.on_device<double>() : nullptr;
+        ea.io_err = w->pin_err.on_device<int32_t>();
+        ea.io_t_max = w->base.t_max; ea.io_seed = w->base.seed;
+        ea.act_episode = nullptr;
+    }
     if (w->timing) HIP_TRY(hipEventRecord(w->ev0, s));
     HIP_TRY(launch_episode(ea, s));
     if (w->timing) HIP_TRY(hipEventRecord(w->ev1, s));
@@ -1424,7 +1431,7 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
     if (out_rewards) io.rewards_out = w->pin_rewards.on_device<double>();
     if (out_actions) io.actions_out = w->pin_actions.on_device<int32_t>();
     io.err_out = w->pin_err.on_device<int32_t>();
-    HIP_TRY(launch_world_unpack(io, s));
+    if (!fused) HIP_TRY(launch_world_unpack(io, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (w->timing) {
         float ms = 0.f;
@@ -1455,6 +1462,103 @@ EPI_API int32_t epi_world_step_greedy(epi_world* w, const double* gauss, int32_t
                                       double* out_rewards, int32_t* out_actions) {
     if (!w) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_step_greedy: null handle");
     return world_step_impl(w, nullptr, true, gauss, t_max, out_states, out_rewards, out_actions);
+}
+
+// `steps` consecutive WorldToy.stepOneGreedy calls without leaving the device (the trainer's evaluation loop,
+// MutliTrainer.scala:137-141): per step one launch of the network kernel (DDQNAgent.actGreedy for every instance and
+// country) and one of the episode kernel, all enqueued back to back; one synchronisation at the end.
+EPI_API int32_t epi_world_rollout_greedy(epi_world* w, epi_agents* agents, int32_t steps, int32_t t_max, double* i_series,
+                                         int32_t* arrival, double* peak, epi_state* out_states) {
+    if (!w) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_rollout_greedy: null handle");
+    if (steps < 0) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_rollout_greedy: steps = %d", steps);
+    const int n = w->n, npad = w->npad, B = w->batch;
+    const size_t cells = (size_t)B * npad, compact = (size_t)B * n;
+    AgentsNetView view{};
+    if (agents) {
+        int32_t rc = agents_net_view(agents, &view);
+        if (rc) return rc;
+        if (view.device != w->device) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_rollout_greedy: the agents live on device %d, the world on device %d", view.device, w->device);
+        if (view.n_agents < n) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_rollout_greedy: %d agents for %d countries (one agent per node, WorldToy.scala:50)", view.n_agents, n);
+    } else if (!w->mlp_set) {
+        return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_rollout_greedy: pass the nodes' agents or call epi_world_set_mlp first");
+    }
+    HIP_TRY(hipSetDevice(w->device));
+    hipStream_t s = nullptr;
+    // Validation.arrivalTime / peakI count from the first step of this call; the error table starts clean
+    HIP_TRY(hipMemsetAsync(w->work.arrival.p, 0xff, cells * sizeof(int32_t), s));
+    HIP_TRY(hipMemsetAsync(w->work.peak.p, 0, cells * sizeof(int32_t), s));
+    HIP_TRY(hipMemsetAsync(w->work.err.p, 0, (size_t)B * 4 * sizeof(int32_t), s));
+    if (i_series && steps > 0) HIP_TRY(w->series_dev.ensure(sizeof(double) * (size_t)steps * compact));
+    // env noise: the next `steps` draws of every country's own stream (env.scala:42,91), a table [chunk][npad]
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, steps), ((size_t)8 << 20) / (size_t)npad));
+    std::vector<double> hz((size_t)chunk * npad, 0.0);
+    HIP_TRY(w->noise_tab.ensure(hz.size() * sizeof(double)));
+
+    MlpArgs ma{};
+    ma.rows = B * n; ma.n = n; ma.npad = npad; ma.count = B;
+    ma.state_t_max = w->base.t_max;
+    ma.st = w->work.st.as<int32_t>(); ma.cap = w->work.cap.as<double>(); ma.tcur = w->work.tcur.as<int32_t>();
+    ma.plane = cells;
+    if (agents) {
+        ma.nl = view.nl; ma.nets = view.nets; ma.net_stride = view.net_stride; ma.per_country = 1;
+        ma.clip_ptr = view.clip_ptr; ma.clip_stride = view.clip_stride; ma.clip_q = 0.0;
+    } else {
+        w->mlp.fill(ma);
+    }
+    ma.act_episode = w->act_dev.as<int8_t>();
+
+    EpisodeArgs ea{};
+    ea.n = n; ea.npad = npad; ea.count = B;
+    ea.seed_idx = w->seed_idx; ea.n_travel = 0; ea.g_begin = 0; ea.g_stride = 1;
+    ea.step_t_max = t_max;
+    ea.validate = w->validate;
+    w->graph.fill(ea);
+    ea.qseed = nullptr; ea.sumw_seed = nullptr; ea.qtop_seed = nullptr; ea.qval_seed = nullptr;
+    if (w->graph.sparse) ea.exports = w->work.exports.as<int32_t>();
+    ea.beta0 = w->beta0.as<double>(); ea.beta_rows = 1;
+    ea.cst = w->cst.as<double>();
+    ea.actions = nullptr; ea.act_episode = w->act_dev.as<int8_t>();
+    ea.noise = w->noise_tab.as<double>(); ea.noise_episode = nullptr;
+    ea.st = w->work.st.as<int32_t>(); ea.cap = w->work.cap.as<double>(); ea.tcur = w->work.tcur.as<int32_t>();
+    ea.arrival = w->work.arrival.as<int32_t>(); ea.peak = w->work.peak.as<int32_t>(); ea.err = w->work.err.as<int32_t>();
+    ea.rwd = w->rwd.as<RewardConsts>(); ea.reward_out = w->reward_dev.as<double>();
+    ea.flow_s = w->flow_s.as<int32_t>(); ea.flow_i = w->flow_i.as<int32_t>();
+    ea.series_i = i_series ? w->series_dev.as<double>() : nullptr;
+    ea.series_t0 = 0;
+    for (int k0 = 0; k0 < steps; k0 += chunk) {
+        const int kn = std::min(chunk, steps - k0);
+        if (k0 > 0) HIP_TRY(hipStreamSynchronize(s));   // the previous chunk's table is still being read
+        for (int k = 0; k < kn; ++k)
+            for (int c = 0; c < n; ++c) hz[(size_t)k * npad + c] = w->env_rnd[c].nextGaussian();
+        HIP_TRY(hipMemcpyAsync(w->noise_tab.p, hz.data(), (size_t)kn * npad * sizeof(double), hipMemcpyHostToDevice, s));
+        ea.noise_t0 = k0;
+        for (int k = k0; k < k0 + kn; ++k) {
+            HIP_TRY(launch_mlp(ma, s));
+            ea.t_begin = k; ea.t_end = k + 1;
+            HIP_TRY(launch_episode(ea, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));   // hz is reused by the next chunk (pageable memory: the copy above is staged)
+    }
+    if (steps > 0) w->have_flows = true;
+    // results
+    if (arrival || peak) {
+        HIP_TRY(w->arr_out.ensure(sizeof(int32_t) * compact));
+        HIP_TRY(w->peak_out.ensure(sizeof(double) * compact));
+        LossArgs la{};
+        la.n = n; la.npad = npad; la.count = B; la.steps = steps;
+        la.arrival = ea.arrival; la.peak = ea.peak;
+        la.loss = nullptr; la.arrival_out = w->arr_out.as<int32_t>(); la.peak_out = w->peak_out.as<double>();
+        HIP_TRY(launch_loss(la, s));
+        if (arrival) HIP_TRY(hipMemcpy(arrival, w->arr_out.p, sizeof(int32_t) * compact, hipMemcpyDeviceToHost));
+        if (peak) HIP_TRY(hipMemcpy(peak, w->peak_out.p, sizeof(double) * compact, hipMemcpyDeviceToHost));
+    }
+    if (i_series && steps > 0)
+        HIP_TRY(hipMemcpy(i_series, w->series_dev.p, sizeof(double) * (size_t)steps * compact, hipMemcpyDeviceToHost));
+    if (out_states) {
+        int32_t rc = world_download_states(w, out_states);
+        if (rc) return rc;
+    }
+    return collect_errors(w->work.err.as<int32_t>(), B, 0);
 }
 
 EPI_API int32_t epi_world_set_timing(epi_world* w, int32_t on) {

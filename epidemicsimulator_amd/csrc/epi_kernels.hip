@@ -210,6 +210,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(W > R ? 
             peak = max(peak, i3);                      // Validation.peakI
             last_flow_s = movedS;
             last_flow_i = movedI;
+            if (a.series_i) a.series_i[((size_t)(t - a.series_t0) * a.count + e) * n + tid] = (double)i3;
             const long long tm = (long long)s3 + i3 + sh_r[tid] + sh_d[tid] + sh_v[tid];
             mass_move = tm > 0 ? (unsigned long long)tm : 0ull;
         }
@@ -699,6 +700,7 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                     a.flow_s[eoff + c] = movedS;
                     a.flow_i[eoff + c] = movedI;
                 }
+                if (a.series_i) a.series_i[((size_t)(t - 1 - a.series_t0) * a.count + e) * n + c] = (double)i0;
                 const long long tmv = (long long)s0 + i0 + r0 + d0 + v0;
                 mass_move += tmv > 0 ? (unsigned long long)tmv : 0ull;
             }
@@ -928,15 +930,24 @@ __global__ __launch_bounds__(64) void episode_tiny_kernel(const EpisodeArgs a) {
         int32_t eS = 0, eI = 0;
         unsigned long long mass_local = 0ull;
         if (real) {
-            int act = a.act_episode ? (int)a.act_episode[eoff + c] : (int)a.actions[(size_t)(t - a.act_t0) * NP + c];
+            const size_t cidx = (size_t)e * n + c;   // position in the caller's compact [count][n] arrays
+            int act = a.io_actions ? (int)a.io_actions[cidx]
+                                   : (a.act_episode ? (int)a.act_episode[eoff + c] : (int)a.actions[(size_t)(t - a.act_t0) * NP + c]);
             act = act < 0 ? 0 : (act > 7 ? 7 : act);  // Action.fromId clamps (env.scala:18-20)
-            const double z = a.noise_episode ? a.noise_episode[eoff + c] : a.noise[(size_t)(t - a.noise_t0) * NP + c];
+            const double z = a.io_gauss ? a.io_gauss[cidx]
+                                        : (a.io_gauss_row ? a.io_gauss_row[c]
+                                                          : (a.noise_episode ? a.noise_episode[eoff + c]
+                                                                             : a.noise[(size_t)(t - a.noise_t0) * NP + c]));
             const long long tb = (long long)s + i + r + d + v;
             const LocalOut o = local_step(k, s, i, r, d, v, cap, act, z);
             const long long ta = (long long)o.s + o.i + o.r + o.d + o.v;
             if (a.validate && ta != tb) record_error(sh_err[grp], EPI_ERR_LOCAL_MASS, c, tcur);
             if ((o.s | o.i | o.r | o.d | o.v) < 0) record_error(sh_err[grp], EPI_ERR_INT_RANGE, c, tcur);
-            if (a.rwd) a.reward_out[eoff + c] = reward_of(a.rwd[c], (double)i, (double)d, o, act);
+            if (a.rwd) {
+                const double rw = reward_of(a.rwd[c], (double)i, (double)d, o, act);
+                a.reward_out[eoff + c] = rw;
+                if (a.io_rewards) a.io_rewards[cidx] = rw;
+            }
             s = o.s; i = o.i; r = o.r; d = o.d; v = o.v;
             cap = o.cap;
             tcur += 1;  // env.scala:132
@@ -965,6 +976,7 @@ __global__ __launch_bounds__(64) void episode_tiny_kernel(const EpisodeArgs a) {
             peak = max(peak, i);
             last_flow_s = movedS;
             last_flow_i = movedI;
+            if (a.series_i) a.series_i[((size_t)(t - a.series_t0) * a.count + e) * n + c] = (double)i;
             const long long tm = (long long)s + i + r + d + v;
             mass_move = tm > 0 ? (unsigned long long)tm : 0ull;
         }
@@ -978,10 +990,19 @@ __global__ __launch_bounds__(64) void episode_tiny_kernel(const EpisodeArgs a) {
         // LDS writes; lane c == 0 of the group cleared the sums above, in program order of the same wave
     }
     __syncthreads();
-    if (live && c == 0 && sh_err[grp][0] != 0 && a.err[e * 4] == 0) {
+    if (a.io_err) {   // this step's table, zeros included: nothing has to clear it beforehand
+        if (live && c < 4) a.err[e * 4 + c] = a.io_err[e * 4 + c] = sh_err[grp][c];
+    } else if (live && c == 0 && sh_err[grp][0] != 0 && a.err[e * 4] == 0) {
         a.err[e * 4 + 1] = sh_err[grp][1];
         a.err[e * 4 + 2] = sh_err[grp][2];
         a.err[e * 4] = sh_err[grp][0];
+    }
+    if (real && a.io_states) {
+        epi_state out;
+        out.s = (double)s; out.i = (double)i; out.r = (double)r; out.d = (double)d; out.v = (double)v;
+        out.hosp_cap = cap;
+        out.t = tcur; out.t_max = a.io_t_max; out.seed = a.io_seed; out.pad_ = 0;
+        a.io_states[(size_t)e * n + c] = out;
     }
     if (real) {
         a.st[0 * plane + eoff + c] = s;
@@ -1124,35 +1145,55 @@ hipError_t launch_loss(const LossArgs& a, hipStream_t s) {
 // DDQNAgent.actGreedy: State.features -> MLP.predict -> first argmax (env.scala:26-30,
 // MLP.scala:12-22, DDQNAgent.scala:22-23).  Every dot product is accumulated left to right with a
 // separate multiply and add, as `row.view.zip(x).map(w*xi).sum` does.
-// A workgroup of 128 threads evaluates MLP_ROWS states; thread u owns hidden unit u.
+// A workgroup evaluates MLP_ROWS states with one network; thread u owns hidden unit u.  With per-country
+// networks (every WorldToy node asks its own agent) blockIdx.y is the country and the rows of a workgroup
+// are episodes of that country.
 // ---------------------------------------------------------------------------------------------
-constexpr int MLP_ROWS = 16;
-constexpr int MLP_MAXH = 128;
+constexpr int MLP_MAXROWS = 16;
+constexpr int MLP_MAXH = 256;
+constexpr int MLP_LOADS = 16;   // weights fetched together: a lone wave has nothing else to hide a load behind
 
-__global__ __launch_bounds__(128) void mlp_greedy_kernel(const MlpArgs a) {
-    __shared__ double sh_x[MLP_ROWS][8];
-    __shared__ double sh_h1[MLP_ROWS][MLP_MAXH];
-    __shared__ double sh_h2[MLP_ROWS][MLP_MAXH];
-    __shared__ double sh_y[MLP_ROWS][8];
+static size_t mlp_lds_bytes(int H, int rows) { return (size_t)(2 * rows * 8 + 2 * rows * H) * sizeof(double); }
+
+// ROWS = states per workgroup (1, 2, 4, 8 or 16): a single world's evaluation has one state per network.
+template <int ROWS>
+__global__ __launch_bounds__(256) void mlp_greedy_kernel(const MlpArgs a) {
+    extern __shared__ double mlp_sh[];
+    const int H = a.nl.H, Hp = a.nl.Hp;
+    double* sh_x = mlp_sh;                   // [ROWS][8]
+    double* sh_y = sh_x + ROWS * 8;          // [ROWS][8]
+    double* sh_h1 = sh_y + ROWS * 8;         // [ROWS][H]
+    double* sh_h2 = sh_h1 + ROWS * H;        // [ROWS][H]
     const int tid = threadIdx.x;
-    const int H = a.hidden;
-    const int row0 = blockIdx.x * MLP_ROWS;
+    const int cfix = a.per_country ? (int)blockIdx.y : 0;
+    const double* __restrict__ net = a.nets + (a.per_country ? (size_t)cfix * a.net_stride : 0);
+    // row r of this workgroup -> (episode, country); false past the end
+    auto locate = [&](int r, int& e, int& c) {
+        if (a.per_country) {
+            e = blockIdx.x * ROWS + r;
+            c = cfix;
+            return e < a.count;
+        }
+        const int row = blockIdx.x * ROWS + r;
+        e = row / a.n;
+        c = row - e * a.n;
+        return row < a.rows;
+    };
 
-    if (tid < MLP_ROWS) {
-        const int row = row0 + tid;
+    if (tid < ROWS) {
         double f[7] = {0, 0, 0, 0, 0, 0, 0};
-        if (row < a.rows) {
+        int e, c;
+        if (locate(tid, e, c)) {
             double s, i, r, d, v, cap;
             int32_t t, tmax;
             if (a.st) {
-                const int e = row / a.n, c = row % a.n;
                 const size_t idx = (size_t)e * a.npad + c;
                 s = (double)a.st[0 * a.plane + idx]; i = (double)a.st[1 * a.plane + idx];
                 r = (double)a.st[2 * a.plane + idx]; d = (double)a.st[3 * a.plane + idx];
                 v = (double)a.st[4 * a.plane + idx];
                 cap = a.cap[idx]; t = a.tcur[idx]; tmax = a.state_t_max;
             } else {
-                const epi_state& st = a.states[row];
+                const epi_state& st = a.states[(size_t)e * a.n + c];
                 s = st.s; i = st.i; r = st.r; d = st.d; v = st.v; cap = st.hosp_cap; t = st.t; tmax = st.t_max;
             }
             const double N = fmax(1.0, s + i + r + d);
@@ -1160,72 +1201,123 @@ __global__ __launch_bounds__(128) void mlp_greedy_kernel(const MlpArgs a) {
             f[5] = i / fmax(1.0, cap);
             f[6] = (double)t / (double)(tmax > 1 ? tmax : 1);
         }
-        for (int k = 0; k < 7; ++k) sh_x[tid][k] = f[k];
+        for (int k = 0; k < 7; ++k) sh_x[tid * 8 + k] = f[k];
+    }
+    // the first weights of the second layer are on their way while the first layer is computed
+    const double* __restrict__ W2T = net + a.nl.w2t();
+    double wn[MLP_LOADS];
+    if (tid < H) {
+#pragma unroll
+        for (int j = 0; j < MLP_LOADS; ++j) wn[j] = W2T[(size_t)j * Hp + tid];   // rows past H are zero padding (Hp >= 64)
     }
     __syncthreads();
     if (tid < H) {
         double w[7];
-        for (int k = 0; k < 7; ++k) w[k] = a.W1[tid * 7 + k];
-        const double b = a.b1 ? a.b1[tid] : 0.0;
-        for (int r = 0; r < MLP_ROWS; ++r) {
-            double acc = w[0] * sh_x[r][0];
-            for (int k = 1; k < 7; ++k) acc = acc + w[k] * sh_x[r][k];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) w[k] = net[a.nl.w1t() + (size_t)k * Hp + tid];
+        const double b = net[a.nl.b1() + tid];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            double acc = w[0] * sh_x[r * 8 + 0];
+#pragma unroll
+            for (int k = 1; k < 7; ++k) acc = acc + w[k] * sh_x[r * 8 + k];
             const double z = acc + b;
-            sh_h1[r][tid] = z > 0 ? z : 0.0;
+            sh_h1[r * H + tid] = z > 0 ? z : 0.0;
         }
     }
     __syncthreads();
     if (tid < H) {
-        double acc[MLP_ROWS];
-        {
-            const double w = a.W2T[tid];
+        double acc[ROWS];
+        for (int k0 = 0; k0 < H; k0 += MLP_LOADS) {
+            double wc[MLP_LOADS];
 #pragma unroll
-            for (int r = 0; r < MLP_ROWS; ++r) acc[r] = w * sh_h1[r][0];
+            for (int j = 0; j < MLP_LOADS; ++j) wc[j] = wn[j];
+            if (k0 + MLP_LOADS < H) {
+#pragma unroll
+                for (int j = 0; j < MLP_LOADS; ++j) wn[j] = W2T[(size_t)(k0 + MLP_LOADS + j) * Hp + tid];
+            }
+#pragma unroll
+            for (int j = 0; j < MLP_LOADS; ++j) {
+                const int k = k0 + j;
+                if (k < H) {
+#pragma unroll
+                    for (int r = 0; r < ROWS; ++r) {
+                        const double p = wc[j] * sh_h1[r * H + k];
+                        acc[r] = (k == 0) ? p : acc[r] + p;
+                    }
+                }
+            }
         }
-        for (int k = 1; k < H; ++k) {
-            const double w = a.W2T[(size_t)k * H + tid];
+        const double b = net[a.nl.b2() + tid];
 #pragma unroll
-            for (int r = 0; r < MLP_ROWS; ++r) acc[r] = acc[r] + w * sh_h1[r][k];
-        }
-        const double b = a.b2 ? a.b2[tid] : 0.0;
-#pragma unroll
-        for (int r = 0; r < MLP_ROWS; ++r) {
+        for (int r = 0; r < ROWS; ++r) {
             const double z = acc[r] + b;
-            sh_h2[r][tid] = z > 0 ? z : 0.0;
+            sh_h2[r * H + tid] = z > 0 ? z : 0.0;
         }
     }
     __syncthreads();
-    {
-        const int r = tid >> 3, o = tid & 7;  // 16 rows x 8 outputs = 128 threads
-        double acc = a.W3[o * H] * sh_h2[r][0];
-        for (int k = 1; k < H; ++k) acc = acc + a.W3[o * H + k] * sh_h2[r][k];
-        double y = acc + (a.b3 ? a.b3[o] : 0.0);
-        if (isfinite(a.clip_q)) y = fmax(-a.clip_q, fmin(a.clip_q, y));
-        sh_y[r][o] = y;
+    if (tid < ROWS * 8) {
+        const int r = tid >> 3, o = tid & 7;
+        const double* __restrict__ W3 = net + a.nl.w3() + (size_t)o * Hp;
+        double acc = 0.0;
+        for (int k0 = 0; k0 < H; k0 += MLP_LOADS) {
+            double wc[MLP_LOADS];
+#pragma unroll
+            for (int j = 0; j < MLP_LOADS; ++j) wc[j] = W3[k0 + j];   // the row is padded to Hp
+#pragma unroll
+            for (int j = 0; j < MLP_LOADS; ++j) {
+                const int k = k0 + j;
+                if (k < H) {
+                    const double p = wc[j] * sh_h2[r * H + k];
+                    acc = (k == 0) ? p : acc + p;
+                }
+            }
+        }
+        double y = acc + net[a.nl.b3() + o];
+        const double clip = a.clip_ptr ? a.clip_ptr[(size_t)cfix * a.clip_stride] : a.clip_q;
+        if (isfinite(clip)) y = fmax(-clip, fmin(clip, y));
+        sh_y[r * 8 + o] = y;
     }
     __syncthreads();
-    if (tid < MLP_ROWS) {
-        const int row = row0 + tid;
-        if (row < a.rows) {
+    if (tid < ROWS) {
+        int e, c;
+        if (locate(tid, e, c)) {
+            const size_t row = (size_t)e * a.n + c;
             int best = 0;
             for (int o = 1; o < 8; ++o)
-                if (sh_y[tid][o] > sh_y[tid][best]) best = o;
-            if (a.act_episode) {
-                const int e = row / a.n, c = row % a.n;
-                a.act_episode[(size_t)e * a.npad + c] = (int8_t)best;
-            }
+                if (sh_y[tid * 8 + o] > sh_y[tid * 8 + best]) best = o;
+            if (a.act_episode) a.act_episode[(size_t)e * a.npad + c] = (int8_t)best;
             if (a.act_out) a.act_out[row] = best;
             if (a.q_out)
-                for (int o = 0; o < 8; ++o) a.q_out[(size_t)row * 8 + o] = sh_y[tid][o];
+                for (int o = 0; o < 8; ++o) a.q_out[row * 8 + o] = sh_y[tid * 8 + o];
         }
     }
 }
 
+template <int ROWS>
+static hipError_t launch_mlp_rows(const MlpArgs& a, int live, hipStream_t s) {
+    const int H = a.nl.H;
+    const size_t lds = mlp_lds_bytes(H, ROWS);
+    if (lds > 48 * 1024) {   // the attribute is kept per device: set it where it is needed
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_greedy_kernel<ROWS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_lds_bytes(MLP_MAXH, ROWS));
+        if (e != hipSuccess) return e;
+    }
+    const dim3 grid((unsigned)((live + ROWS - 1) / ROWS), a.per_country ? (unsigned)a.n : 1u);
+    hipLaunchKernelGGL(mlp_greedy_kernel<ROWS>, grid, dim3(H > 128 ? 256 : 128), lds, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_mlp(const MlpArgs& a, hipStream_t s) {
     if (a.rows <= 0) return hipSuccess;
-    if (a.hidden < 1 || a.hidden > MLP_MAXH) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mlp_greedy_kernel, dim3((unsigned)((a.rows + MLP_ROWS - 1) / MLP_ROWS)), dim3(128), 0, s, a);
-    return hipGetLastError();
+    const int H = a.nl.H;
+    if (H < 1 || H > MLP_MAXH || a.nl.Hp < H || a.nl.Hp % 64 != 0) return hipErrorInvalidValue;
+    const int live = a.per_country ? a.count : a.rows;   // states that share a network
+    if (live <= 1) return launch_mlp_rows<1>(a, live, s);
+    if (live <= 2) return launch_mlp_rows<2>(a, live, s);
+    if (live <= 4) return launch_mlp_rows<4>(a, live, s);
+    if (live <= 8) return launch_mlp_rows<8>(a, live, s);
+    return launch_mlp_rows<MLP_MAXROWS>(a, live, s);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -85,6 +85,17 @@ struct EpisodeArgs {
     int32_t* flow_s;         // [count][npad] movedS of the last step (WorldToy.scala:106-126)
     int32_t* flow_i;
     unsigned long long* stats;  // optional [32] search statistics: rows, probes, cold starts, ties, histogram
+    // compact caller-side arrays of the batched world step, read and written by the kernel itself (small worlds:
+    // episode_tiny_kernel; one-step launches only).  They sit in page-locked host memory mapped into the device.
+    const int32_t* io_actions;   // [count][n] caller's action ids (clamped as Action.fromId), or NULL
+    const double* io_gauss;      // [count][n] noise draws, or NULL: io_gauss_row[n], one draw per country for all instances
+    const double* io_gauss_row;
+    epi_state* io_states;        // [count][n] State records out (t_max and seed from io_t_max / io_seed), or NULL
+    double* io_rewards;          // [count][n] or NULL
+    int32_t* io_err;             // [count][4] copy of the error table
+    int32_t io_t_max, io_seed;
+    double* series_i;        // optional [.][count][n]: I of every country after step t at index t - series_t0
+    int series_t0;           // (the series the trainer's evaluation collects, MutliTrainer.scala:139)
 };
 
 struct InitArgs {
@@ -102,16 +113,57 @@ struct LossArgs {
     double* loss; int32_t* arrival_out; double* peak_out;  // arrival_out/peak_out [count][n] optional
 };
 
+// One network of DDQNAgent (MLP.scala:4-13: 7 -> H -> H -> 8) in device memory, every matrix with row stride Hp
+// (hidden rounded up to 64, zero padded):
+//   W1t[7][Hp]  b1[Hp]  W2[Hp][Hp] (row = output)  W2t[Hp][Hp] (row = input)  b2[Hp]  W3[8][Hp]  b3[8]
+struct NetLayout {
+    int H, Hp;
+    __host__ __device__ size_t w1t() const { return 0; }
+    __host__ __device__ size_t b1() const { return (size_t)7 * Hp; }
+    __host__ __device__ size_t w2() const { return b1() + Hp; }
+    __host__ __device__ size_t w2t() const { return w2() + (size_t)Hp * Hp; }
+    __host__ __device__ size_t b2() const { return w2t() + (size_t)Hp * Hp; }
+    __host__ __device__ size_t w3() const { return b2() + Hp; }
+    __host__ __device__ size_t b3() const { return w3() + (size_t)8 * Hp; }
+    __host__ __device__ size_t size() const { return b3() + 8; }
+};
+
+// Host image of one network in the device layout from the reference's arrays W1[H][7], b1[H], W2[H][H], b2[H],
+// W3[8][H], b3[8] (MLP.scala:4-13); NULL biases are zero.  `out` holds nl.size() doubles.
+inline void pack_net(const NetLayout& nl, const double* W1, const double* b1, const double* W2, const double* b2,
+                     const double* W3, const double* b3, double* out) {
+    for (size_t k = 0; k < nl.size(); ++k) out[k] = 0.0;
+    const int H = nl.H, Hp = nl.Hp;
+    for (int i = 0; i < H; ++i) {
+        for (int j = 0; j < 7; ++j) out[nl.w1t() + (size_t)j * Hp + i] = W1[(size_t)i * 7 + j];
+        out[nl.b1() + i] = b1 ? b1[i] : 0.0;
+        for (int j = 0; j < H; ++j) {
+            out[nl.w2() + (size_t)i * Hp + j] = W2[(size_t)i * H + j];
+            out[nl.w2t() + (size_t)j * Hp + i] = W2[(size_t)i * H + j];
+        }
+        out[nl.b2() + i] = b2 ? b2[i] : 0.0;
+    }
+    for (int o = 0; o < 8; ++o) {
+        for (int j = 0; j < H; ++j) out[nl.w3() + (size_t)o * Hp + j] = W3[(size_t)o * H + j];
+        out[nl.b3() + o] = b3 ? b3[o] : 0.0;
+    }
+}
+
+// DDQNAgent.actGreedy for `rows` (episode, country) pairs, row = e * n + c.  With per_country != 0 country c asks
+// network c (nets + c * net_stride): the per-node agents of WorldToy.scala:46-65.
 struct MlpArgs {
-    int rows;          // (episode, country) pairs, row = e * n + c
-    int n, npad, hidden;
+    int rows;          // (episode, country) pairs
+    int n, npad, count;  // countries, padded plane width, episodes (rows = count * n)
     int state_t_max;
     const int32_t* st; const double* cap; const int32_t* tcur; size_t plane;  // episode state layout
-    const epi_state* states;  // alternative input: rows states (AoS), used when st == NULL
-    const double* W1; const double* b1;   // [h][7]
-    const double* W2T; const double* b2;  // [h(k)][h(u)] transposed
-    const double* W3; const double* b3;   // [8][h]
-    double clip_q;
+    const epi_state* states;  // alternative input: rows states (AoS), used when st == NULL (then n = 1)
+    NetLayout nl;
+    const double* nets;       // network(s) in NetLayout form
+    size_t net_stride;        // doubles from country c's network to country c+1's (per_country)
+    int per_country;
+    double clip_q;            // clamp of the outputs (MLP.scala:21), used when clip_ptr == NULL
+    const double* clip_ptr;   // per-country clamp: clip_ptr[c * clip_stride]
+    int clip_stride;
     int8_t* act_episode;  // [count][npad] (when st != NULL)
     int32_t* act_out;     // [rows] optional
     double* q_out;        // [rows][8] optional
@@ -155,6 +207,18 @@ struct GravityArgs {
     double a, b, g, k, cap_row;
     double* W;             // [n][n] out
 };
+
+// Device view of the networks an epi_agents handle holds (epi_agents.hip).
+struct AgentsNetView {
+    int device, n_agents;
+    NetLayout nl;
+    const double* nets; size_t net_stride;
+    const double* clip_ptr; int clip_stride;
+};
+}  // namespace epi
+struct epi_agents;
+namespace epi {
+int32_t agents_net_view(epi_agents* g, AgentsNetView* v);
 
 hipError_t launch_gravity(const GravityArgs& a, hipStream_t s);
 hipError_t launch_world_pack(const WorldIoArgs& a, hipStream_t s);

@@ -229,6 +229,7 @@ typedef struct epi_world_desc {
 } epi_world_desc;
 
 typedef struct epi_world epi_world;
+typedef struct epi_agents epi_agents;   /* the DDQN learners declared further down */
 
 epi_world *epi_world_create(const epi_world_desc *desc);
 /* One WorldToy.stepOne (:83-145) for every instance with caller-chosen actions[batch][n].
@@ -246,6 +247,17 @@ int32_t epi_world_result_buffers(epi_world *w, epi_state **states, double **rewa
 /* WorldToy.stepOneGreedy (:172-235): actions = argmax Q(features) with the weights set below. */
 int32_t epi_world_step_greedy(epi_world *w, const double *gauss, int32_t t_max, epi_state *out_states,
                               double *out_rewards, int32_t *out_actions);
+/* The trainer's greedy evaluation loop (MutliTrainer.scala:137-141): `steps` consecutive WorldToy.stepOneGreedy(t_max)
+ * calls (WorldToy.scala:172-235) for every instance, without a host round trip per step.  With agents != NULL country
+ * c asks the online network of agent c (DDQNAgent.actGreedy, DDQNAgent.scala:22-23; one agent per node,
+ * WorldToy.scala:50; same device as the world); with NULL every country asks the network of epi_world_set_mlp.
+ * Env noise comes from the engine's JVM-compatible per-country streams, advanced exactly as `steps` single calls
+ * would.  Outputs, each optional: i_series[steps][batch][n] = s2.i after every step (what the trainer appends to
+ * its series, :139); arrival[batch][n] = Validation.arrivalTime(series, 10.0) and peak[batch][n] =
+ * Validation.peakI(series) over the steps of this call (Validation.scala:15-22); out_states[batch][n] = the final
+ * states.  snapshotStates / resetToInitial / restoreStates around it are epi_world_get_states / _reset / _set_states. */
+int32_t epi_world_rollout_greedy(epi_world *w, epi_agents *agents, int32_t steps, int32_t t_max, double *i_series,
+                                 int32_t *arrival, double *peak, epi_state *out_states);
 int32_t epi_world_set_mlp(epi_world *w, int32_t hidden, const double *W1, const double *b1, const double *W2,
                           const double *b2, const double *W3, const double *b3, double clip_q);
 int32_t epi_world_get_states(epi_world *w, epi_state *out);       /* snapshotStates :75 */
@@ -268,8 +280,6 @@ typedef struct epi_learn_hyper {
     int32_t target_update_every;
     int32_t max_need;            /* largest batch * gradAccumSteps epi_agents_learn will be asked for */
 } epi_learn_hyper;
-
-typedef struct epi_agents epi_agents;
 
 /* n_agents fresh agents (two networks each from MLP.scala:5-9, empty replay buffers whose shuffle stream is
  * Random(123)) on `device`.  Returns NULL on failure. */
