@@ -36,17 +36,45 @@ def algorithmic_bytes_per_country_step(n, conn):
     return 8.0 * n + 68.0
 
 
-def measured_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
-    (FETCH_SIZE and WRITE_SIZE are collected in rocprofv3 runs of their own, see profiles/collect.sh and
-    profiles/summarize.py; they cannot be read inside this process).  None when no summary exists."""
+VALU_PEAK_GINST = 1024 * 2.4 / 4.0   # G wave-instructions/s: 256 CUs x 4 SIMDs, 2.4 GHz, a wave64 instruction takes 4 cycles
+
+
+def profile_summary(workload):
+    """The newest committed rocprofv3 summary of this workload under profiles/ (PMC counters are collected in
+    rocprofv3 runs of their own, see profiles/collect.sh and profiles/summarize.py; they cannot be read inside
+    this process).  ({}, None) when none exists."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_%s.json" % workload)))
     if not files:
-        return None, None
+        return {}, None
     with open(files[-1]) as f:
-        d = json.load(f)
-    return d.get("traffic_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+        return json.load(f), os.path.relpath(files[-1], ROOT)
+
+
+def measured_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/."""
+    d, src = profile_summary(workload)
+    return d.get("traffic_bytes_per_launch"), src
+
+
+def valu_roofline(workload, country_steps, kernel_ms, traffic):
+    """The resource that limits the episode kernels in practice: VALU issue.  Wave instructions per country-step come
+    from the committed SQ_INSTS_VALU pass, the time from this run's HIP events; next to it the HBM rate actually
+    measured (counter bytes over this run's kernel time)."""
+    d, src = profile_summary(workload)
+    per_cs = d.get("valu_insts_per_country_step")
+    if per_cs is None and d.get("counters_one_sweep", {}).get("SQ_INSTS_VALU") and d.get("bench_line"):
+        per_cs = d["counters_one_sweep"]["SQ_INSTS_VALU"] / d["bench_line"]["config"]["country_steps_per_step"]
+    if not per_cs or kernel_ms <= 0:
+        return None
+    achieved = per_cs * country_steps / (kernel_ms * 1e-3) / 1e9
+    out = {"bound": "valu-issue", "achieved": achieved, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+           "frac": achieved / VALU_PEAK_GINST, "valu_wave_insts_per_country_step": per_cs,
+           "salu_wave_insts_per_country_step": d.get("salu_insts_per_country_step"),
+           "source": "%s: SQ_INSTS_VALU of a separate rocprofv3 --pmc pass of this command; time = this run's HIP events; "
+                     "peak = 1,024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (fp64 instructions measure 4.8 cycles, "
+                     "tools/op_rate.hip, so the real ceiling is lower)" % src}
+    return out
 
 
 def host_cores():
@@ -485,8 +513,10 @@ def main():
             "rccl_ranks": dist.get_world_size() if use_dist else 0,
             "kernel_ms_per_step_by_rank": [round(r[0], 3) for r in per_rank_all],
             "grid_points_by_rank": [int(r[1]) for r in per_rank_all]},
+        "roofline_valu": valu_roofline(wl["name"], k_cs, k_ms, traffic) if world == 1 else None,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "hbm_measured_gbs": (traffic * k_launches / (k_ms * 1e-3) / 1e9) if traffic and k_ms > 0 else None,
                      "traffic_source": ("%s: per-launch (FETCH_SIZE*2 + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes "
                                         "of this command" % traffic_src) if traffic_src else None,
                      "kernel": "episode_csr_kernel" if isinstance(wl["conn"], tuple) else (

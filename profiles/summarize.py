@@ -93,8 +93,13 @@ def main():
         "traffic_bytes_per_launch": (fetch_bytes + write_bytes) / max(1, launches),
         "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
         "l2_hit_rate": c.get("TCC_HIT_sum", 0.0) / max(1.0, c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 0.0)),
+        "valu_insts_per_launch": c.get("SQ_INSTS_VALU", 0.0) / max(1, launches),
+        "salu_insts_per_launch": c.get("SQ_INSTS_SALU", 0.0) / max(1, launches),
         "counters_one_sweep": c,
     }
+    cs_per_launch = summary["algorithmic_bytes_per_launch"] / bench["roofline"]["algorithmic_bytes_per_country_step"]
+    summary["valu_insts_per_country_step"] = summary["valu_insts_per_launch"] / max(1.0, cs_per_launch)
+    summary["salu_insts_per_country_step"] = summary["salu_insts_per_launch"] / max(1.0, cs_per_launch)
     with open(out + ".json", "w") as f:
         json.dump(summary, f, indent=1)
         f.write("\n")
@@ -110,6 +115,13 @@ def main():
         f.write("| HBM write per launch (WRITE_SIZE x 1024) | %.3e B |\n" % summary["hbm_write_bytes_per_launch"])
         f.write("| algorithmic bytes per launch | %.3e B |\n" % summary["algorithmic_bytes_per_launch"])
         f.write("| L2 hit rate (TCC_HIT / (HIT+MISS)) | %.3f |\n" % summary["l2_hit_rate"])
+        f.write("| measured HBM rate (read + write) / rocprofv3 avg launch | %.1f GB/s |\n" % (
+            summary["traffic_bytes_per_launch"] / (summary["rocprof_avg_launch_ms"] * 1e-3) / 1e9))
+        f.write("| VALU / SALU wave instructions per country-step | %.0f / %.0f |\n" % (
+            summary["valu_insts_per_country_step"], summary["salu_insts_per_country_step"]))
+        f.write("| VALU issue rate: wave instructions / s against 1,024 SIMDs x 2.4 GHz / 4 cycles | %.3g / 6.14e11 = %.2f |\n" % (
+            summary["valu_insts_per_launch"] / (summary["rocprof_avg_launch_ms"] * 1e-3),
+            summary["valu_insts_per_launch"] / (summary["rocprof_avg_launch_ms"] * 1e-3) / 6.144e11))
         for k in sorted(c):
             f.write("| %s (one sweep) | %.4g |\n" % (k, c[k]))
         if "cpu_baseline" in bench:
