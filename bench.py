@@ -100,7 +100,7 @@ def cpu_baseline(wl, base, threads, seconds_target=15.0):
     O.build()
     pops = [c.pop for c in wl["countries"]]
     profs = [util.prof_dict(p) for p in wl["profiles"]]
-    W = util.dense_of(wl["conn"], len(pops))
+    W = wl["conn"] if isinstance(wl["conn"], tuple) else util.dense_of(wl["conn"], len(pops))   # CSR graphs stay CSR
     nt = len(wl["travel"])
     G = len(wl["betas"]) * nt
 

@@ -610,7 +610,9 @@ static double agent_epsilon(const agent *a, const orc_hyper *hp) { /* DDQNAgent.
 typedef struct {
     int32_t n, seed_idx, validate;
     int32_t *pop;
-    double *conn; /* n*n row-major */
+    double *conn; /* n*n row-major, or NULL when the graph is given as CSR below */
+    int32_t *rowptr, *col; /* CSR form of the same matrix: entries that are not stored are weight 0 */
+    double *val;
     orc_env_params *env;
     orc_profile *prof;
     jrand *env_rnd;
@@ -639,8 +641,10 @@ EXPORT void *orc_world_create(int32_t n, const int32_t *pop, const double *conn,
     w->n = n; w->seed_idx = seed_idx; w->validate = validate; w->hp = *hp;
     w->pop = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
     memcpy(w->pop, pop, sizeof(int32_t) * (size_t)n);
-    w->conn = (double *)malloc(sizeof(double) * (size_t)n * n);
-    memcpy(w->conn, conn, sizeof(double) * (size_t)n * n);
+    if (conn) {
+        w->conn = (double *)malloc(sizeof(double) * (size_t)n * n);
+        memcpy(w->conn, conn, sizeof(double) * (size_t)n * n);
+    }
     w->env = (orc_env_params *)malloc(sizeof(orc_env_params) * (size_t)n);
     w->prof = (orc_profile *)malloc(sizeof(orc_profile) * (size_t)n);
     memcpy(w->env, env, sizeof(orc_env_params) * (size_t)n);
@@ -676,8 +680,26 @@ EXPORT void *orc_world_create(int32_t n, const int32_t *pop, const double *conn,
     return w;
 }
 
+/* The same world over a CSR graph (columns ascending inside a row): the mobility loop then walks the stored
+ * entries only.  Entries that are not stored have weight 0: they add +0.0 to the row sum and have raw = 0,
+ * base = 0, fraction 0 in allocateInt, exactly what the dense walk computes for them.                       */
+EXPORT void *orc_world_create_csr(int32_t n, const int32_t *pop, const int32_t *rowptr, const int32_t *col, const double *val,
+                                  int32_t seed_idx, const orc_state *base, const orc_env_params *env, const orc_profile *prof,
+                                  const int32_t *env_seeds, const orc_hyper *hp, int32_t validate) {
+    world *w = (world *)orc_world_create(n, pop, NULL, seed_idx, base, env, prof, env_seeds, hp, validate);
+    size_t nnz = (size_t)rowptr[n];
+    w->rowptr = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    w->col = (int32_t *)malloc(sizeof(int32_t) * (nnz ? nnz : 1));
+    w->val = (double *)malloc(sizeof(double) * (nnz ? nnz : 1));
+    memcpy(w->rowptr, rowptr, sizeof(int32_t) * ((size_t)n + 1));
+    memcpy(w->col, col, sizeof(int32_t) * nnz);
+    memcpy(w->val, val, sizeof(double) * nnz);
+    return w;
+}
+
 EXPORT void orc_world_destroy(void *h) {
     world *w = (world *)h;
+    free(w->rowptr); free(w->col); free(w->val);
     free(w->pop); free(w->conn); free(w->env); free(w->prof); free(w->env_rnd); free(w->agents);
     free(w->init); free(w->cur); free(w->last_a); mlp_free(&w->net);
     if (w->learners) {
@@ -714,7 +736,34 @@ static void mobility_apply(world *w, const orc_state *local, int32_t t_max, int3
     double *wRow = (double *)malloc(sizeof(double) * (size_t)n);
     int32_t *aS = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
     int32_t *aI = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < n && w->rowptr; i++) {   /* CSR graph: the stored entries of row i, the origin's own entry as 0 (:113) */
+        int32_t Si = imax(0, jround_i(local[i].s));
+        int32_t Ii = imax(0, jround_i(local[i].i));
+        int rs = w->rowptr[i], deg = w->rowptr[i + 1] - rs;
+        double sum = 0.0;
+        for (int k = 0; k < deg; k++) {
+            wRow[k] = (w->col[rs + k] == i) ? 0.0 : w->val[rs + k];
+            sum = (k == 0) ? wRow[0] : sum + wRow[k];
+        }
+        double sumW = fmax(0.0, sum);
+        double eS = floor((double)Si * sumW + 1e-9);
+        double eI = floor((double)Ii * sumW + 1e-9);
+        int64_t lS = d2l(eS), lI = d2l(eI);
+        int32_t exportS = (int32_t)(uint32_t)(uint64_t)((int64_t)Si < lS ? (int64_t)Si : lS);
+        int32_t exportI = (int32_t)(uint32_t)(uint64_t)((int64_t)Ii < lI ? (int64_t)Ii : lI);
+        int32_t extra[4], nxS = 0, nxI = 0;
+        orc_alloc_int_sparse(exportS, wRow, w->col + rs, deg, n, aS, extra, 4, &nxS);
+        orc_alloc_int_sparse(exportI, wRow, w->col + rs, deg, n, aI, extra, 4, &nxI);
+        /* units left over for columns that are not stored: the dense walk hands them out, no sparse layout does */
+        if ((nxS | nxI) != 0 && w->err == 0) { w->err = 5; w->err_node = i; w->err_t = local[i].t; }
+        for (int k = 0; k < deg; k++) {
+            int j = w->col[rs + k];
+            if (j != i) { movedS[j] = iadd(movedS[j], aS[k]); movedI[j] = iadd(movedI[j], aI[k]); }
+        }
+        movedS[i] = isub(movedS[i], exportS);
+        movedI[i] = isub(movedI[i], exportI);
+    }
+    for (int i = 0; i < n && !w->rowptr; i++) {
         int32_t Si = imax(0, jround_i(local[i].s));
         int32_t Ii = imax(0, jround_i(local[i].i));
         double sum = 0.0;
@@ -835,15 +884,31 @@ static double rmse(const double *x, int n) { /* :14-17 */
     return sqrt(s / fmax(1.0, nn));
 }
 
-/* Calibrate.rollout :19-82 for one (beta, travelScale).
+/* Calibrate.rollout :19-82 for one (beta, travelScale) over a dense matrix W or, with W == NULL, a CSR graph.
  * Returns arrival[n], peak[n], final[n]; *err = world error code.            */
-EXPORT void orc_rollout(int32_t n, const int32_t *pop, const double *W, int32_t seed_idx, const orc_state *base,
+static void rollout_any(int32_t n, const int32_t *pop, const double *W, const int32_t *rowptr, const int32_t *col,
+                        const double *val, int32_t seed_idx, const orc_state *base,
                         const orc_profile *prof, const orc_hyper *hp, int32_t steps, double beta, double ts,
                         int32_t heterogeneous, int32_t *arrival, double *peak, double *final_i, double *series_out,
                         int32_t *err) {
-    double *Ws = (double *)malloc(sizeof(double) * (size_t)n * n);
-    memcpy(Ws, W, sizeof(double) * (size_t)n * n);
-    orc_scale_row(Ws, n, seed_idx, ts); /* :29 */
+    double *Ws = NULL, *vs = NULL;
+    if (W) {
+        Ws = (double *)malloc(sizeof(double) * (size_t)n * n);
+        memcpy(Ws, W, sizeof(double) * (size_t)n * n);
+        orc_scale_row(Ws, n, seed_idx, ts); /* :29 */
+    } else {
+        /* ToyConn.scaleRow on the stored entries of the seed row: the zeros of the other columns stay zeros and add
+         * +0.0 to the row sum (ToyConn.scala:58-70) */
+        size_t nnz = (size_t)rowptr[n];
+        vs = (double *)malloc(sizeof(double) * (nnz ? nnz : 1));
+        memcpy(vs, val, sizeof(double) * nnz);
+        int rs = rowptr[seed_idx], re = rowptr[seed_idx + 1];
+        double s = 0.0;
+        for (int k = rs; k < re; k++) if (col[k] != seed_idx) { vs[k] *= ts; s += vs[k]; }
+        double cap = fmin(0.2, s);
+        if (s > cap && s > 0) { double sc = cap / s; for (int k = rs; k < re; k++) if (col[k] != seed_idx) vs[k] *= sc; }
+        for (int k = rs; k < re; k++) if (col[k] == seed_idx) vs[k] = 0.0;
+    }
     orc_env_params *env = (orc_env_params *)malloc(sizeof(orc_env_params) * (size_t)n);
     orc_profile *pr = (orc_profile *)malloc(sizeof(orc_profile) * (size_t)n);
     int32_t *seeds = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
@@ -866,7 +931,8 @@ EXPORT void orc_rollout(int32_t n, const int32_t *pop, const double *W, int32_t 
             seeds[c] = 7;
         }
     }
-    world *w = (world *)orc_world_create(n, pop, Ws, seed_idx, base, env, pr, seeds, hp, 1 /* validate = true :64 */);
+    world *w = W ? (world *)orc_world_create(n, pop, Ws, seed_idx, base, env, pr, seeds, hp, 1 /* validate = true :64 */)
+                 : (world *)orc_world_create_csr(n, pop, rowptr, col, vs, seed_idx, base, env, pr, seeds, hp, 1);
     double *series = (double *)malloc(sizeof(double) * (size_t)n * (size_t)(steps > 0 ? steps : 1));
     for (int t = 0; t < steps; t++) { /* :68-73 */
         orc_world_step(w, steps, 0, NULL);
@@ -881,13 +947,24 @@ EXPORT void orc_rollout(int32_t n, const int32_t *pop, const double *W, int32_t 
     if (series_out) memcpy(series_out, series, sizeof(double) * (size_t)n * (size_t)steps);
     *err = w->err;
     orc_world_destroy(w);
-    free(series); free(Ws); free(env); free(pr); free(seeds);
+    free(series); free(Ws); free(vs); free(env); free(pr); free(seeds);
+}
+
+/* Calibrate.rollout :19-82 for one (beta, travelScale).
+ * Returns arrival[n], peak[n], final[n]; *err = world error code.            */
+EXPORT void orc_rollout(int32_t n, const int32_t *pop, const double *W, int32_t seed_idx, const orc_state *base,
+                        const orc_profile *prof, const orc_hyper *hp, int32_t steps, double beta, double ts,
+                        int32_t heterogeneous, int32_t *arrival, double *peak, double *final_i, double *series_out,
+                        int32_t *err) {
+    rollout_any(n, pop, W, NULL, NULL, NULL, seed_idx, base, prof, hp, steps, beta, ts, heterogeneous, arrival, peak, final_i,
+                series_out, err);
 }
 
 /* Calibrate.gridSurface :84-116.  has_arr/has_pk are the Map key-presence masks.
  * Outputs: loss[nb*nts] beta-major; optional arrival/peak [G][n]; best index by
  * strict < (first minimum).  Returns the first nonzero world error code.      */
-EXPORT int32_t orc_grid_surface(int32_t n, const int32_t *pop, const double *W, int32_t seed_idx,
+static int32_t grid_surface_any(int32_t n, const int32_t *pop, const double *W, const int32_t *rowptr, const int32_t *col,
+                                const double *val, int32_t seed_idx,
                                 const orc_state *base, const orc_profile *prof, const orc_hyper *hp,
                                 int32_t steps, const double *betas, int32_t nb, const double *tss, int32_t nts,
                                 const double *t_arrive, const uint8_t *has_arr, const double *t_peak,
@@ -902,7 +979,7 @@ EXPORT int32_t orc_grid_surface(int32_t n, const int32_t *pop, const double *W, 
     for (int b = 0; b < nb; b++)
         for (int k = 0; k < nts; k++) {
             int g = b * nts + k, err = 0;
-            orc_rollout(n, pop, W, seed_idx, base, prof, hp, steps, betas[b], tss[k], heterogeneous, arr, pk, fin, NULL, &err);
+            rollout_any(n, pop, W, rowptr, col, val, seed_idx, base, prof, hp, steps, betas[b], tss[k], heterogeneous, arr, pk, fin, NULL, &err);
             if (err && !first_err) first_err = err;
             for (int c = 0; c < n; c++) {
                 double a = (double)arr[c];
@@ -922,6 +999,27 @@ EXPORT int32_t orc_grid_surface(int32_t n, const int32_t *pop, const double *W, 
     return first_err;
 }
 
+EXPORT int32_t orc_grid_surface(int32_t n, const int32_t *pop, const double *W, int32_t seed_idx,
+                                const orc_state *base, const orc_profile *prof, const orc_hyper *hp,
+                                int32_t steps, const double *betas, int32_t nb, const double *tss, int32_t nts,
+                                const double *t_arrive, const uint8_t *has_arr, const double *t_peak,
+                                const uint8_t *has_pk, int32_t heterogeneous, double *loss, int32_t *arrival_out,
+                                double *peak_out, int32_t *best_idx, double *best_loss) {
+    return grid_surface_any(n, pop, W, NULL, NULL, NULL, seed_idx, base, prof, hp, steps, betas, nb, tss, nts, t_arrive, has_arr,
+                            t_peak, has_pk, heterogeneous, loss, arrival_out, peak_out, best_idx, best_loss);
+}
+
+/* The same over a CSR graph: O(stored entries) per world step instead of O(n^2). */
+EXPORT int32_t orc_grid_surface_csr(int32_t n, const int32_t *pop, const int32_t *rowptr, const int32_t *col, const double *val,
+                                    int32_t seed_idx, const orc_state *base, const orc_profile *prof, const orc_hyper *hp,
+                                    int32_t steps, const double *betas, int32_t nb, const double *tss, int32_t nts,
+                                    const double *t_arrive, const uint8_t *has_arr, const double *t_peak,
+                                    const uint8_t *has_pk, int32_t heterogeneous, double *loss, int32_t *arrival_out,
+                                    double *peak_out, int32_t *best_idx, double *best_loss) {
+    return grid_surface_any(n, pop, NULL, rowptr, col, val, seed_idx, base, prof, hp, steps, betas, nb, tss, nts, t_arrive, has_arr,
+                            t_peak, has_pk, heterogeneous, loss, arrival_out, peak_out, best_idx, best_loss);
+}
+
 /* Timed leg for bench.py's cpu_baseline: runs `n_points` grid points starting at
  * flat index g0 (beta-major) and returns the country-steps executed.          */
 EXPORT int64_t orc_bench_points(int32_t n, const int32_t *pop, const double *W, int32_t seed_idx,
@@ -936,6 +1034,28 @@ EXPORT int64_t orc_bench_points(int32_t n, const int32_t *pop, const double *W, 
     for (int g = g0; g < g0 + n_points; g++) {
         int err = 0;
         orc_rollout(n, pop, W, seed_idx, base, prof, hp, steps, betas[g / nts], tss[g % nts], heterogeneous, arr, pk, fin, NULL, &err);
+        for (int c = 0; c < n; c++) cs += pk[c] + (double)arr[c];
+        done += (int64_t)n * steps;
+    }
+    *checksum = cs;
+    free(arr); free(pk); free(fin);
+    return done;
+}
+
+/* The same timed leg over a CSR graph. */
+EXPORT int64_t orc_bench_points_csr(int32_t n, const int32_t *pop, const int32_t *rowptr, const int32_t *col, const double *val,
+                                    int32_t seed_idx, const orc_state *base, const orc_profile *prof, const orc_hyper *hp,
+                                    int32_t steps, const double *betas, int32_t nb, const double *tss, int32_t nts,
+                                    int32_t heterogeneous, int32_t g0, int32_t n_points, double *checksum) {
+    int32_t *arr = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    double *pk = (double *)malloc(sizeof(double) * (size_t)n);
+    double *fin = (double *)malloc(sizeof(double) * (size_t)n);
+    double cs = 0.0; int64_t done = 0;
+    (void)nb;
+    for (int g = g0; g < g0 + n_points; g++) {
+        int err = 0;
+        rollout_any(n, pop, NULL, rowptr, col, val, seed_idx, base, prof, hp, steps, betas[g / nts], tss[g % nts], heterogeneous,
+                    arr, pk, fin, NULL, &err);
         for (int c = 0; c < n; c++) cs += pk[c] + (double)arr[c];
         done += (int64_t)n * steps;
     }

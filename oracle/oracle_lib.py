@@ -63,8 +63,10 @@ def lib():
         L.orc_strict_log.restype = C.c_double
         L.orc_strict_log.argtypes = [C.c_double]
         L.orc_world_create.restype = C.c_void_p
+        L.orc_world_create_csr.restype = C.c_void_p
         L.orc_peak_i.restype = C.c_double
         L.orc_bench_points.restype = C.c_int64
+        L.orc_bench_points_csr.restype = C.c_int64
         L.orc_learner_create.restype = C.c_void_p
         L.orc_world_learner.restype = C.c_void_p
         L.orc_learner_learn.restype = C.c_double
@@ -230,10 +232,18 @@ class World:
     def __init__(self, pops, conn, seed_idx, base, envs, profiles, env_seeds, hp=None, validate=True):
         self.n = len(pops)
         pops = np.ascontiguousarray(pops, dtype=np.int32)
-        conn = np.ascontiguousarray(conn, dtype=np.float64)
         seeds = np.ascontiguousarray(env_seeds, dtype=np.int32)
         env_arr = (EnvParams * self.n)(*envs)
         self.hp = hp or default_hyper()
+        if isinstance(conn, tuple):   # (rowptr, col, val): the mobility loop walks the stored entries only
+            rp = np.ascontiguousarray(conn[0], dtype=np.int32); col = np.ascontiguousarray(conn[1], dtype=np.int32)
+            val = np.ascontiguousarray(conn[2], dtype=np.float64)
+            self.h = C.c_void_p(lib().orc_world_create_csr(
+                C.c_int32(self.n), _p(pops, C.c_int32), _p(rp, C.c_int32), _p(col, C.c_int32), _p(val, C.c_double),
+                C.c_int32(seed_idx), C.byref(base), env_arr, profiles_array(profiles), _p(seeds, C.c_int32),
+                C.byref(self.hp), C.c_int32(int(validate))))
+            return
+        conn = np.ascontiguousarray(conn, dtype=np.float64)
         self.h = C.c_void_p(lib().orc_world_create(
             C.c_int32(self.n), _p(pops, C.c_int32), _p(conn, C.c_double), C.c_int32(seed_idx), C.byref(base),
             env_arr, profiles_array(profiles), _p(seeds, C.c_int32), C.byref(self.hp), C.c_int32(int(validate))))
@@ -322,7 +332,6 @@ def grid_surface(pops, W, seed_idx, base, profiles, steps, betas, tss, t_arrive,
                  heterogeneous=True, hp=None):
     n = len(pops)
     pops = np.ascontiguousarray(pops, dtype=np.int32)
-    W = np.ascontiguousarray(W, dtype=np.float64)
     betas = np.ascontiguousarray(betas, dtype=np.float64); tss = np.ascontiguousarray(tss, dtype=np.float64)
     ta = np.ascontiguousarray(t_arrive, dtype=np.float64); tp = np.ascontiguousarray(t_peak, dtype=np.float64)
     ha = np.ascontiguousarray(has_arr, dtype=np.uint8); hk = np.ascontiguousarray(has_pk, dtype=np.uint8)
@@ -330,6 +339,17 @@ def grid_surface(pops, W, seed_idx, base, profiles, steps, betas, tss, t_arrive,
     G = len(betas) * len(tss)
     loss = np.zeros(G); arr = np.zeros((G, n), dtype=np.int32); pk = np.zeros((G, n))
     bi = C.c_int32(0); bl = C.c_double(0)
+    if isinstance(W, tuple):   # CSR graph (rowptr, col, val): O(stored entries) per world step
+        rp = np.ascontiguousarray(W[0], dtype=np.int32); col = np.ascontiguousarray(W[1], dtype=np.int32)
+        val = np.ascontiguousarray(W[2], dtype=np.float64)
+        err = lib().orc_grid_surface_csr(C.c_int32(n), _p(pops, C.c_int32), _p(rp, C.c_int32), _p(col, C.c_int32), _p(val, C.c_double),
+                                         C.c_int32(seed_idx), C.byref(base), profiles_array(profiles), C.byref(hp), C.c_int32(steps),
+                                         _p(betas, C.c_double), C.c_int32(len(betas)), _p(tss, C.c_double), C.c_int32(len(tss)),
+                                         _p(ta, C.c_double), _p(ha, C.c_uint8), _p(tp, C.c_double), _p(hk, C.c_uint8),
+                                         C.c_int32(int(heterogeneous)), _p(loss, C.c_double), _p(arr, C.c_int32), _p(pk, C.c_double),
+                                         C.byref(bi), C.byref(bl))
+        return dict(loss=loss, arrival=arr, peak=pk, best_idx=bi.value, best_loss=bl.value, err=err)
+    W = np.ascontiguousarray(W, dtype=np.float64)
     err = lib().orc_grid_surface(C.c_int32(n), _p(pops, C.c_int32), _p(W, C.c_double), C.c_int32(seed_idx), C.byref(base),
                                  profiles_array(profiles), C.byref(hp), C.c_int32(steps), _p(betas, C.c_double),
                                  C.c_int32(len(betas)), _p(tss, C.c_double), C.c_int32(len(tss)), _p(ta, C.c_double),
@@ -341,10 +361,18 @@ def grid_surface(pops, W, seed_idx, base, profiles, steps, betas, tss, t_arrive,
 def bench_points(pops, W, seed_idx, base, profiles, steps, betas, tss, heterogeneous, g0, n_points, hp=None):
     n = len(pops)
     pops = np.ascontiguousarray(pops, dtype=np.int32)
-    W = np.ascontiguousarray(W, dtype=np.float64)
     betas = np.ascontiguousarray(betas, dtype=np.float64); tss = np.ascontiguousarray(tss, dtype=np.float64)
     hp = hp or default_hyper()
     cs = C.c_double(0)
+    if isinstance(W, tuple):
+        rp = np.ascontiguousarray(W[0], dtype=np.int32); col = np.ascontiguousarray(W[1], dtype=np.int32)
+        val = np.ascontiguousarray(W[2], dtype=np.float64)
+        done = lib().orc_bench_points_csr(C.c_int32(n), _p(pops, C.c_int32), _p(rp, C.c_int32), _p(col, C.c_int32), _p(val, C.c_double),
+                                          C.c_int32(seed_idx), C.byref(base), profiles_array(profiles), C.byref(hp), C.c_int32(steps),
+                                          _p(betas, C.c_double), C.c_int32(len(betas)), _p(tss, C.c_double), C.c_int32(len(tss)),
+                                          C.c_int32(int(heterogeneous)), C.c_int32(g0), C.c_int32(n_points), C.byref(cs))
+        return int(done), cs.value
+    W = np.ascontiguousarray(W, dtype=np.float64)
     done = lib().orc_bench_points(C.c_int32(n), _p(pops, C.c_int32), _p(W, C.c_double), C.c_int32(seed_idx), C.byref(base),
                                   profiles_array(profiles), C.byref(hp), C.c_int32(steps), _p(betas, C.c_double),
                                   C.c_int32(len(betas)), _p(tss, C.c_double), C.c_int32(len(tss)),

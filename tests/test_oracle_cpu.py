@@ -302,3 +302,43 @@ def test_learner_restatements_agree(oracle):
     for i in range(8):
         R.observe(O.State(1000 - i, i, 0, 0, 0, 100.0, i, 999, 1, 0), 0, 0.0, O.State(999 - i, i + 1, 0, 0, 0, 100.0, i + 1, 999, 1, 0), False)
     assert R.replay_size() == 4 and sorted(R.sample(4)) == [0, 1, 2, 3]
+
+
+def test_csr_world_equals_dense_world(oracle):
+    """The oracle's CSR walk of the mobility loop (stored entries only) against its dense walk of the densified
+    matrix: states, rewards and flows of every step, and whole grid surfaces including the seed row's scaleRow."""
+    import epidemicsimulator_amd as E
+    from epidemicsimulator_amd import synth
+    from tests import util
+    n = 260
+    countries, xy = synth.make_countries(n, 99)
+    rp, col, val = synth.gravity_csr(countries, xy, 99, mean_degree=7.0)
+    # one row stores its own diagonal entry and one an explicit zero weight
+    i = 5
+    if i not in col[rp[i]:rp[i + 1]]:
+        k = rp[i] + int(np.searchsorted(col[rp[i]:rp[i + 1]], i))
+        col = np.insert(col, k, i); val = np.insert(val, k, 0.05); rp = rp.copy(); rp[i + 1:] += 1
+    val[rp[9]] = 0.0
+    dense = util.dense_of((rp, col, val), n)
+    rng = np.random.default_rng(4)
+    base = O.State(0, 0, 0, 0, 0, 10_000.0, 0, 80, 1, 0)
+    envs = [O.EnvParams(0.2 + 0.3 * rng.random(), 0.12, 0.008, 0.05, 5.0, 0.2) for _ in range(n)]
+    profs = [util.prof_dict(c) for c in countries]
+    a = O.World([c.pop for c in countries], dense, 3, base, envs, profs, list(range(100, 100 + n)))
+    b = O.World([c.pop for c in countries], (rp, col, val), 3, base, envs, profs, list(range(100, 100 + n)))
+    for step in range(12):
+        acts = rng.integers(0, 8, n); gauss = rng.normal(size=n)
+        ra, msa, mia = a.step_given(acts, gauss, 80)
+        rb, msb, mib = b.step_given(acts, gauss, 80)
+        assert a.error()[0] == 0 and b.error()[0] == 0
+        np.testing.assert_array_equal(ra, rb); np.testing.assert_array_equal(msa, msb); np.testing.assert_array_equal(mia, mib)
+        assert [x.tup() for x in a.states()] == [x.tup() for x in b.states()]
+    wl = synth.small_workload(8, 2, 3, 25, seed=99)
+    wl["countries"], wl["profiles"], wl["conn"], wl["seed_idx"] = countries, countries, (rp, col, val), 5
+    wl["t_arrive"], wl["t_peak"] = synth.targets(n, 25, 99)
+    bs = synth.base_state(25)
+    d = util.oracle_grid(wl, bs); s = util.oracle_grid(wl, bs, sparse=True)
+    assert d["err"] == 0 and s["err"] == 0
+    for key in ("loss", "arrival", "peak"):
+        np.testing.assert_array_equal(d[key], s[key])
+    assert (d["best_idx"], d["best_loss"]) == (s["best_idx"], s["best_loss"])
