@@ -612,6 +612,36 @@ EPI_API int32_t epi_grid_argmin(const double* loss, int32_t count, int32_t* best
 // ================================================================================================
 // batched unit operations
 // ================================================================================================
+// The unit operations below (allocateInt, env.step, actGreedy for caller-held arrays) are called once per
+// reference call by a shim that forwards EpidemicEnv.allocateInt or env.step one at a time: their device staging
+// is kept per device for the life of the process and only grows, so a call allocates nothing once the sizes have
+// been seen.  One caller at a time per device (a mutex serialises the rest).
+namespace {
+struct UnitScratch {
+    std::mutex mu;
+    DevBuf b[8];
+    MlpDevice mlp;                 // network of the last epi_mlp_greedy_batch call ...
+    std::vector<double> mlp_key;   // ... and the weights it was built from (re-uploaded only when they change)
+};
+UnitScratch* unit_scratch(int device) {
+    static std::mutex mu;
+    static UnitScratch* per_device[kMaxScratchDevices];   // never freed: it must outlive every caller
+    if (device < 0 || device >= kMaxScratchDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!per_device[device]) per_device[device] = new UnitScratch();
+    return per_device[device];
+}
+thread_local int g_unit_device = 0;
+}  // namespace
+
+EPI_API int32_t epi_set_device(int32_t device) {
+    int32_t rc = use_device(device);
+    if (rc) return rc;
+    if (device >= kMaxScratchDevices) return fail(EPI_ERR_UNSUPPORTED, "epi_set_device: devices 0..%d", kMaxScratchDevices - 1);
+    g_unit_device = device;
+    return EPI_OK;
+}
+
 EPI_API int32_t epi_alloc_int_batch(const int32_t* totals, const double* w, int32_t n, int32_t batch, int32_t* out) {
     if (n < 0 || batch < 0) return fail(EPI_ERR_BAD_ARGUMENT, "epi_alloc_int_batch: negative size");
     if (n == 0 || batch == 0) return EPI_OK;
@@ -620,18 +650,19 @@ EPI_API int32_t epi_alloc_int_batch(const int32_t* totals, const double* w, int3
     const size_t cells = (size_t)n * batch;
     for (size_t k = 0; k < cells; ++k)
         if (!std::isfinite(w[k]) || w[k] < 0.0) return fail(EPI_ERR_BAD_ARGUMENT, "epi_alloc_int_batch: weight %zu = %g must be finite and >= 0", k, w[k]);
-    int32_t rc = use_device(0);
+    int32_t rc = use_device(g_unit_device);
     if (rc) return rc;
-    DevBuf dt, dw, dout;
+    UnitScratch* us = unit_scratch(g_unit_device);
+    std::lock_guard<std::mutex> lock(us->mu);
+    DevBuf &dt = us->b[0], &dw = us->b[1], &dout = us->b[2];
     HIP_TRY(dt.ensure(sizeof(int32_t) * (size_t)batch));
     HIP_TRY(dw.ensure(sizeof(double) * cells));
     HIP_TRY(dout.ensure(sizeof(int32_t) * cells));
-    HIP_TRY(hipMemcpy(dt.p, totals, sizeof(int32_t) * (size_t)batch, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dw.p, w, sizeof(double) * cells, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(dt.p, totals, sizeof(int32_t) * (size_t)batch, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(dw.p, w, sizeof(double) * cells, hipMemcpyHostToDevice, nullptr));
     AllocBatchArgs a{n, dense_slots_for(n) * 64, batch, dt.as<int32_t>(), dw.as<double>(), dout.as<int32_t>()};
     HIP_TRY(launch_alloc_batch(a, nullptr));
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, dout.p, sizeof(int32_t) * cells, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, dout.p, sizeof(int32_t) * cells, hipMemcpyDeviceToHost));   // waits for the launch
     return EPI_OK;
 }
 
@@ -651,9 +682,11 @@ EPI_API int32_t epi_env_step_batch(const epi_env_params* env, const epi_profile*
             !std::isfinite(s.hosp_cap) || !std::isfinite(gauss[b]))
             return fail(EPI_ERR_BAD_ARGUMENT, "epi_env_step_batch: row %d holds a non-finite value", b);
     }
-    int32_t rc = use_device(0);
+    int32_t rc = use_device(g_unit_device);
     if (rc) return rc;
-    DevBuf de, dp, di, da, dg, dout, dr, dd;
+    UnitScratch* us = unit_scratch(g_unit_device);
+    std::lock_guard<std::mutex> lock(us->mu);
+    DevBuf &de = us->b[0], &dp = us->b[1], &di = us->b[2], &da = us->b[3], &dg = us->b[4], &dout = us->b[5], &dr = us->b[6], &dd = us->b[7];
     const size_t B = (size_t)batch;
     HIP_TRY(de.ensure(B * sizeof(epi_env_params)));
     HIP_TRY(dp.ensure(B * sizeof(epi_profile)));
@@ -663,16 +696,15 @@ EPI_API int32_t epi_env_step_batch(const epi_env_params* env, const epi_profile*
     HIP_TRY(dout.ensure(B * sizeof(epi_state)));
     HIP_TRY(dr.ensure(B * sizeof(double)));
     HIP_TRY(dd.ensure(B));
-    HIP_TRY(hipMemcpy(de.p, env, B * sizeof(epi_env_params), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dp.p, prof, B * sizeof(epi_profile), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(di.p, in, B * sizeof(epi_state), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(da.p, action, B * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dg.p, gauss, B * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(de.p, env, B * sizeof(epi_env_params), hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(dp.p, prof, B * sizeof(epi_profile), hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(di.p, in, B * sizeof(epi_state), hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(da.p, action, B * sizeof(int32_t), hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(dg.p, gauss, B * sizeof(double), hipMemcpyHostToDevice, nullptr));
     EnvBatchArgs a{batch, de.as<epi_env_params>(), dp.as<epi_profile>(), di.as<epi_state>(), da.as<int32_t>(),
                    dg.as<double>(), dout.as<epi_state>(), dr.as<double>(), dd.as<uint8_t>()};
     HIP_TRY(launch_env_batch(a, nullptr));
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, dout.p, B * sizeof(epi_state), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, dout.p, B * sizeof(epi_state), hipMemcpyDeviceToHost));   // waits for the launch
     if (reward) HIP_TRY(hipMemcpy(reward, dr.p, B * sizeof(double), hipMemcpyDeviceToHost));
     if (done) HIP_TRY(hipMemcpy(done, dd.p, B, hipMemcpyDeviceToHost));
     return EPI_OK;
@@ -684,16 +716,32 @@ EPI_API int32_t epi_mlp_greedy_batch(const epi_state* states, int32_t batch, int
     if (batch < 0) return fail(EPI_ERR_BAD_ARGUMENT, "epi_mlp_greedy_batch: negative batch");
     if (batch == 0) return EPI_OK;
     if (!states || !W1 || !W2 || !W3) return fail(EPI_ERR_BAD_ARGUMENT, "epi_mlp_greedy_batch: null pointer");
-    int32_t rc = use_device(0);
+    if (hidden < 1 || hidden > 256) return fail(EPI_ERR_UNSUPPORTED, "hidden = %d: the device network supports 1..256 units", hidden);
+    int32_t rc = use_device(g_unit_device);
     if (rc) return rc;
-    MlpDevice m;
-    rc = m.upload(hidden, W1, b1, W2, b2, W3, b3, clip_q);
-    if (rc) return rc;
-    DevBuf ds, dq, da;
+    UnitScratch* us = unit_scratch(g_unit_device);
+    std::lock_guard<std::mutex> lock(us->mu);
+    {   // the network is uploaded again only when hidden, clip or any weight differs from the last call's
+        const size_t h = (size_t)hidden;
+        std::vector<double> key;
+        key.reserve(2 + h * 7 + h * h + 8 * h + 2 * h + 8 + 3);
+        key.push_back((double)hidden); key.push_back(clip_q);
+        key.insert(key.end(), W1, W1 + h * 7); key.insert(key.end(), W2, W2 + h * h); key.insert(key.end(), W3, W3 + 8 * h);
+        key.push_back(b1 ? 1.0 : 0.0); if (b1) key.insert(key.end(), b1, b1 + h);
+        key.push_back(b2 ? 1.0 : 0.0); if (b2) key.insert(key.end(), b2, b2 + h);
+        key.push_back(b3 ? 1.0 : 0.0); if (b3) key.insert(key.end(), b3, b3 + 8);
+        if (key.size() != us->mlp_key.size() || std::memcmp(key.data(), us->mlp_key.data(), key.size() * sizeof(double)) != 0) {
+            rc = us->mlp.upload(hidden, W1, b1, W2, b2, W3, b3, clip_q);
+            if (rc) { us->mlp_key.clear(); return rc; }
+            us->mlp_key.swap(key);
+        }
+    }
+    MlpDevice& m = us->mlp;
+    DevBuf &ds = us->b[0], &dq = us->b[1], &da = us->b[2];
     HIP_TRY(ds.ensure((size_t)batch * sizeof(epi_state)));
     HIP_TRY(dq.ensure((size_t)batch * 8 * sizeof(double)));
     HIP_TRY(da.ensure((size_t)batch * sizeof(int32_t)));
-    HIP_TRY(hipMemcpy(ds.p, states, (size_t)batch * sizeof(epi_state), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(ds.p, states, (size_t)batch * sizeof(epi_state), hipMemcpyHostToDevice, nullptr));
     MlpArgs a{};
     a.rows = batch; a.n = 1; a.npad = 1; a.count = batch;
     a.states = ds.as<epi_state>();

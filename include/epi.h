@@ -76,6 +76,12 @@ int32_t epi_last_status(void);
 /* Number of usable HIP devices (0 when none). */
 int32_t epi_device_count(void);
 
+/* Device of the calling thread's unit operations below (epi_alloc_int*, epi_env_step_batch, epi_mlp_greedy_batch);
+ * 0 until set.  Handles (epi_grid, epi_world, epi_agents) name their device in their descriptors instead.  The
+ * unit operations keep their device staging for the life of the process: after the first call of a given size
+ * they allocate nothing. */
+int32_t epi_set_device(int32_t device);
+
 /* ---- EpidemicEnv.allocateInt (env.scala:241-254) ------------------------------------------- */
 /* out[n] = largest-remainder split of `total` over weights w[n]. */
 int32_t epi_alloc_int(int32_t total, const double *w, int32_t n, int32_t *out);

@@ -126,6 +126,29 @@ def test_mlp_greedy_matches_oracle(epi):
         assert act[k] == int(np.argmax(want))
 
 
+def test_unit_ops_keep_their_staging(epi):
+    """The per-call entry points reuse device staging between calls (growing, shrinking and growing sizes again) and
+    the cached network of epi_mlp_greedy_batch is replaced when any weight changes."""
+    rng = np.random.default_rng(5)
+    assert epi.lib().epi_set_device(0) == 0
+    assert epi.lib().epi_set_device(99) != 0
+    for n, B in ((1000, 8), (6, 1), (300, 40), (6, 1)):
+        w = rng.random((B, n)); totals = rng.integers(0, 10**9, B).astype(np.int32)
+        got = epi.EpidemicEnv.allocate_int_batch(totals, w)
+        for b in range(B):
+            np.testing.assert_array_equal(got[b], O.alloc_int(totals[b], w[b]))
+    W = [x.copy() for x in epi.mlp_init(128)]
+    st = [epi.State(9e5, 1e3 + k, 50, 3, 0, 1e4, k, 300, 1) for k in range(5)]
+    q1, a1 = epi.mlp_greedy(st, W, 10.0)
+    q2, _ = epi.mlp_greedy(st[:2], W, 10.0)
+    np.testing.assert_array_equal(q2, q1[:2])
+    W[2][3, 17] += 0.25                                   # one output weight changes: the cached network must not be reused
+    q3, _ = epi.mlp_greedy(st, W, 10.0)
+    assert not np.array_equal(q3[:, 3], q1[:, 3]) and np.array_equal(q3[:, 2], q1[:, 2])
+    q4, _ = epi.mlp_greedy(st, W, 0.01)                   # so does the clamp
+    assert np.abs(q4).max() <= 0.01
+
+
 # ---------------------------------------------------------------- WorldToy.stepOne (WorldToy.scala:83-145)
 def _world_pair(epi, countries, conn, batch, seed=3):
     n = len(countries)
