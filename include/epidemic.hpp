@@ -324,6 +324,7 @@ public:
     Agents& operator=(const Agents&) = delete;
 
     int size() const { return (int)hps_.size(); }
+    epi_agents* handle() const { return h_; }
     void observe(const std::vector<int32_t>& ids, const std::vector<Transition>& trs) {  // DDQNAgent.scala:34
         std::vector<epi_state> s, s2;
         std::vector<int32_t> a;
@@ -555,6 +556,32 @@ public:
         return collect(out, rew, acts);
     }
 
+    // The periodic greedy evaluation of the trainer (MutliTrainer.scala:128-161): snapshot, reset, maxEvalSteps
+    // stepOneGreedy calls kept on the device (epi_world_rollout_greedy), the four metrics per country, restore.
+    std::map<std::string, double> evaluateGreedy(int maxEvalSteps = 800) {
+        const int n = (int)nodes.size();
+        const auto saved = snapshotStates();
+        resetToInitial();
+        if (!(learning_ && pool_)) ensureMlp();
+        std::vector<double> series((size_t)maxEvalSteps * n);
+        check(epi_world_rollout_greedy(h_, learning_ && pool_ ? pool_->handle() : nullptr, maxEvalSteps, maxEvalSteps,
+                                       series.data(), nullptr, nullptr, nullptr));
+        std::map<std::string, double> m;
+        for (int c = 0; c < n; ++c) {
+            std::vector<double> is((size_t)maxEvalSteps), isN((size_t)maxEvalSteps);
+            for (int k = 0; k < maxEvalSteps; ++k) {
+                is[k] = series[(size_t)k * n + c];
+                isN[k] = is[k] / std::max(1.0, (double)nodes[c].pop);
+            }
+            m["eval_arrival_" + nodes[c].name] = (double)Validation::arrivalTime(is, 10.0);
+            m["eval_peakI_" + nodes[c].name] = Validation::peakI(is);
+            m["eval/arrivalN_" + nodes[c].name] = (double)Validation::arrivalTime(isN, 1e-4);
+            m["eval/peakI_norm_" + nodes[c].name] = Validation::peakI(isN);
+        }
+        restoreStates(saved);
+        return m;
+    }
+
     std::pair<std::vector<int>, std::vector<int>> lastFlows() {
         std::vector<int32_t> s(nodes.size()), i(nodes.size());
         check(epi_world_last_flows(h_, s.data(), i.data()));
@@ -676,7 +703,7 @@ using Surface = std::pair<std::vector<Row>, std::pair<double, std::pair<double, 
 inline Surface gridSurface(const HyperParams& hp, const TrainConfig& cfg, const State& base, int seedIdx, const Targets& targets,
                            const std::vector<double>& betaGrid, const std::vector<double>& travelScales, bool /*validate*/ = true,
                            bool heterogeneous = true, const std::vector<Geo::Country>& countries = ToyConn::C(),
-                           const Matrix& conn = ToyConn::W()) {
+                           const Matrix& conn = ToyConn::W(), const std::vector<int32_t>& devices = {}) {
     const int n = (int)countries.size();
     std::pair<double, double> bestPair{betaGrid.empty() ? 0.25 : betaGrid[0], travelScales.empty() ? 1.0 : travelScales[0]};
     if (betaGrid.empty() || travelScales.empty()) return {{}, {1.7976931348623157e308, bestPair}};
@@ -701,7 +728,10 @@ inline Surface gridSurface(const HyperParams& hp, const TrainConfig& cfg, const 
     std::vector<double> loss(betaGrid.size() * travelScales.size());
     int32_t bestIdx = 0;
     double bestLoss = 0;
-    check(epi_calibrate_grid(&d, loss.data(), nullptr, nullptr, &bestIdx, &bestLoss));
+    if (devices.empty())
+        check(epi_calibrate_grid(&d, loss.data(), nullptr, nullptr, &bestIdx, &bestLoss));
+    else   // several GPUs of the node: one engine per listed device, loss pieces all-gathered with RCCL inside the library
+        check(epi_calibrate_grid_multi(&d, devices.data(), (int32_t)devices.size(), loss.data(), nullptr, nullptr, &bestIdx, &bestLoss));
     std::vector<Row> rows;
     for (size_t b = 0; b < betaGrid.size(); ++b)
         for (size_t k = 0; k < travelScales.size(); ++k) rows.emplace_back(betaGrid[b], travelScales[k], loss[b * travelScales.size() + k]);

@@ -124,6 +124,17 @@ static void evalDeterminismSpec() {
     EXPECT(w1->nodes[0].s.i == 330000.0 && w1->nodes[1].s.i == 0.0);
     w1->restoreStates(snap);
     EXPECT(w1->snapshotStates() == snap);
+    // the trainer's evaluation on the device equals the step-by-step one and leaves the world as it was
+    {
+        auto w4 = makeWorld();
+        const auto held = w4->snapshotStates();
+        const auto m = w4->evaluateGreedy(100);
+        EXPECT(w4->snapshotStates() == held);
+        auto w5 = makeWorld();
+        std::vector<double> usa = runEvalSeries(*w5, 100);
+        EXPECT(m.at("eval_peakI_USA") == Validation::peakI(usa));
+        EXPECT(m.at("eval_arrival_USA") == (double)Validation::arrivalTime(usa, 10.0));
+    }
     // stepOne conserves world mass (validate = true would throw otherwise)
     HyperParams hp;
     WorldToy w3(hp, State{0, 0, 0, 0, 0, 10000, 0, 120, 42}, 0, ToyConn::W(), [] { return std::make_shared<EpidemicEnv>(); }, nullptr, true);
@@ -132,6 +143,19 @@ static void evalDeterminismSpec() {
     for (int k = 0; k < 30; ++k) w3.stepOne(120);
     for (auto& nd : w3.nodes) after += nd.s.s + nd.s.i + nd.s.r + nd.s.d + nd.s.v;
     EXPECT(before == after);
+}
+
+// CalibrationSpec's sweep cut over several engines (the multi-GPU entry point, here all on device 0)
+static void calibrationMulti() {
+    HyperParams hp;
+    TrainConfig cfg;
+    cfg.epochs = 1; cfg.stepsPerEpoch = 60;
+    State base{1000000, 0, 0, 0, 0, 10000, 0, 60, 3};
+    Calibrate::Targets tg;
+    tg.tArrive["Japan"] = 20.0; tg.peakI["USA"] = 5e4;
+    const auto one = Calibrate::gridSurface(hp, cfg, base, 0, tg, {0.24, 0.26, 0.3}, {0.8, 1.0});
+    const auto three = Calibrate::gridSurface(hp, cfg, base, 0, tg, {0.24, 0.26, 0.3}, {0.8, 1.0}, true, true, ToyConn::C(), ToyConn::W(), {0, 0, 0});
+    EXPECT(one == three);
 }
 
 // HeterogeneitySpec.scala:18-29
@@ -248,7 +272,7 @@ int main() {
         const char* name;
         void (*fn)();
     } specs[] = {{"ValidationSpec", validationSpec}, {"MobilitySpec", mobilitySpec}, {"CalibrationSpec", calibrationSpec},
-                 {"EvalDeterminismSpec", evalDeterminismSpec}, {"HeterogeneitySpec", heterogeneitySpec}, {"WireFormats", wireFormats}, {"ReplayBufferSpec", replayBufferSpec}};
+                 {"EvalDeterminismSpec", evalDeterminismSpec}, {"HeterogeneitySpec", heterogeneitySpec}, {"CalibrationMulti", calibrationMulti}, {"WireFormats", wireFormats}, {"ReplayBufferSpec", replayBufferSpec}};
     for (auto& s : specs) {
         const int before = failures;
         try {
