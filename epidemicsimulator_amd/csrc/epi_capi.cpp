@@ -73,34 +73,6 @@ void scale_row_inplace(double* row, int n, int self, double factor) {
     row[self] = 0.0;
 }
 
-// Normalised row for the mobility split: wRow_j = (j == i) ? 0 : W_ij, sumW = wRow.sum
-// (left to right), export factor max(0, sumW) (WorldToy.scala:113-114) and q_j = wRow_j / sumW,
-// the first of allocateInt's two roundings (env.scala:244).  A non-positive sum makes allocateInt
-// return zeros (env.scala:243): q is left at 0.
-int32_t normalise_row(const double* wrow_in, int n, int self, double* q_out, double* sumw_out) {
-    double sum = 0.0;
-    for (int j = 0; j < n; ++j) {
-        const double w = (j == self) ? 0.0 : wrow_in[j];
-        if (!std::isfinite(w) || w < 0.0)
-            return fail(EPI_ERR_BAD_ARGUMENT, "connection weight (%d,%d) = %g: weights must be finite and >= 0", self, j, w);
-        sum = (j == 0) ? w : sum + w;
-    }
-    *sumw_out = std::fmax(0.0, sum);
-    for (int j = 0; j < n; ++j) {
-        const double w = (j == self) ? 0.0 : wrow_in[j];
-        q_out[j] = (sum > 0.0) ? w / sum : 0.0;
-    }
-    return EPI_OK;
-}
-
-// The kTopWeights largest entries of a normalised row, descending, zero padded.
-void top_weights(const double* q, int n, double* out) {
-    std::vector<double> v(q, q + n);
-    const int k = n < kTopWeights ? n : kTopWeights;
-    std::partial_sort(v.begin(), v.begin() + k, v.end(), [](double a, double b) { return a > b; });
-    for (int j = 0; j < kTopWeights; ++j) out[j] = j < k ? v[j] : 0.0;
-}
-
 // Dense row-major copy of the connection matrix from either input form.
 int32_t densify(int n, const double* conn, const int32_t* rowptr, const int32_t* col, const double* val,
                 std::vector<double>& W) {
@@ -134,7 +106,8 @@ static size_t long_row_slots(int deg) {
 struct GraphTables {
     int n = 0, npad = 0;
     DevBuf q, sumw, pop, qtop;
-    std::vector<double> W;  // dense host copy (seed-row variants are derived from it)
+    DevBuf d_W;             // dense graphs: the matrix itself, kept while the handle's tables are being built
+    std::vector<double> W;  // dense host copy (checked for finite, non-negative weights before the upload)
     // sparse mode (n > kMaxDenseN): CSR arrays on the device, raw weights on the host
     bool sparse = false;
     int max_deg = 0, lane_deg = 0;
@@ -314,21 +287,28 @@ struct GraphTables {
         npad = dense_slots_for(n) * 64;
         int32_t rc = densify(n, conn, rowptr, col, val, W);
         if (rc) return rc;
-        std::vector<double> hq((size_t)n * npad, 0.0), hs((size_t)npad, 0.0);
-        for (int i = 0; i < n; ++i) {
-            rc = normalise_row(&W[(size_t)i * n], n, i, &hq[(size_t)i * npad], &hs[i]);
-            if (rc) return rc;
-        }
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                const double w = W[(size_t)i * n + j];
+                if (j != i && (!std::isfinite(w) || w < 0.0))
+                    return fail(EPI_ERR_BAD_ARGUMENT, "connection weight (%d,%d) = %g: weights must be finite and >= 0", i, j, w);
+            }
         std::vector<int32_t> hp((size_t)npad, 0);
         for (int c = 0; c < n; ++c) {
             if (pop_[c] < 0) return fail(EPI_ERR_BAD_ARGUMENT, "pop[%d] = %d is negative", c, pop_[c]);
             hp[c] = pop_[c];
         }
-        std::vector<double> ht((size_t)n * kTopWeights, 0.0);
-        for (int i = 0; i < n; ++i) top_weights(&hq[(size_t)i * npad], n, &ht[(size_t)i * kTopWeights]);
-        HIP_TRY(q.upload(hq));
-        HIP_TRY(qtop.upload(ht));
-        HIP_TRY(sumw.upload(hs));
+        // the tables are built on the device from the uploaded matrix (prepare_rows_kernel): normalised rows, row
+        // sums, top-weight lists
+        HIP_TRY(d_W.upload(W));
+        HIP_TRY(q.ensure(sizeof(double) * (size_t)n * npad));
+        HIP_TRY(qtop.ensure(sizeof(double) * (size_t)n * kTopWeights));
+        HIP_TRY(sumw.ensure(sizeof(double) * (size_t)npad));
+        HIP_TRY(hipMemsetAsync(sumw.p, 0, sizeof(double) * (size_t)npad, nullptr));
+        PrepareRowsArgs pa{};
+        pa.n = n; pa.npad = npad; pa.W = d_W.as<double>(); pa.n_rows = n; pa.seed_idx = 0; pa.travel = nullptr;
+        pa.q = q.as<double>(); pa.sumw = sumw.as<double>(); pa.qtop = qtop.as<double>();
+        HIP_TRY(launch_prepare_rows(pa, nullptr));
         HIP_TRY(pop.upload(hp));
         return EPI_OK;
     }
@@ -824,21 +804,27 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
         HIP_TRY(G->qseed.upload(hq));
         HIP_TRY(G->sumw_seed.upload(hs));
     } else {
-        std::vector<double> hq((size_t)(d->n_travel > 0 ? d->n_travel : 1) * npad, 0.0), hs((size_t)(d->n_travel > 0 ? d->n_travel : 1), 0.0);
-        std::vector<double> row((size_t)n);
-        for (int k = 0; k < d->n_travel; ++k) {
+        // ToyConn.scaleRow(W, seedIdx, ts) for every travel scale, its normalised row, row sum and top weights: one
+        // workgroup per scale on the device, from the matrix the graph tables were built from
+        const int nt = d->n_travel > 0 ? d->n_travel : 1;
+        for (int k = 0; k < d->n_travel; ++k)
             if (!std::isfinite(d->travel[k]) || d->travel[k] < 0.0) return fail(EPI_ERR_BAD_ARGUMENT, "grid: travel scale %d = %g", k, d->travel[k]);
-            std::memcpy(row.data(), &G->graph.W[(size_t)d->seed_idx * n], sizeof(double) * (size_t)n);
-            scale_row_inplace(row.data(), n, d->seed_idx, d->travel[k]);
-            rc = normalise_row(row.data(), n, d->seed_idx, &hq[(size_t)k * npad], &hs[k]);
-            if (rc) return rc;
+        HIP_TRY(G->qseed.ensure(sizeof(double) * (size_t)nt * npad));
+        HIP_TRY(G->qtop_seed.ensure(sizeof(double) * (size_t)nt * kTopWeights));
+        HIP_TRY(G->sumw_seed.ensure(sizeof(double) * (size_t)nt));
+        if (d->n_travel > 0) {
+            DevBuf d_travel;
+            HIP_TRY(d_travel.upload(std::vector<double>(d->travel, d->travel + d->n_travel)));
+            PrepareRowsArgs pa{};
+            pa.n = n; pa.npad = npad; pa.W = G->graph.d_W.as<double>(); pa.n_rows = d->n_travel; pa.seed_idx = d->seed_idx;
+            pa.travel = d_travel.as<double>();
+            pa.q = G->qseed.as<double>(); pa.sumw = G->sumw_seed.as<double>(); pa.qtop = G->qtop_seed.as<double>();
+            HIP_TRY(launch_prepare_rows(pa, nullptr));
+            HIP_TRY(hipDeviceSynchronize());   // d_travel goes out of scope
         }
-        std::vector<double> ht((size_t)(d->n_travel > 0 ? d->n_travel : 1) * kTopWeights, 0.0);
-        for (int k = 0; k < d->n_travel; ++k) top_weights(&hq[(size_t)k * npad], n, &ht[(size_t)k * kTopWeights]);
-        HIP_TRY(G->qseed.upload(hq));
-        HIP_TRY(G->qtop_seed.upload(ht));
-        HIP_TRY(G->sumw_seed.upload(hs));
     }
+    G->graph.d_W.release();   // the tables are complete: the matrix itself is not read again
+    G->graph.W.clear(); G->graph.W.shrink_to_fit();
     // per-country environments (Calibrate.scala:31-51)
     const Hyper hp = to_hyper(d->hp);
     {
@@ -1257,6 +1243,9 @@ static int32_t world_build(epi_world* Wd, const epi_world_desc* d) {
     Wd->base = d->base;
     rc = Wd->graph.build(d->n, d->pop, d->conn, d->csr_rowptr, d->csr_col, d->csr_val);
     if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    Wd->graph.d_W.release();   // the tables are complete: the matrix itself is not read again
+    Wd->graph.W.clear(); Wd->graph.W.shrink_to_fit();
     const int n = d->n, npad = Wd->graph.npad;
     Wd->npad = npad;
     std::vector<double> hb((size_t)npad, 0.0), hc((size_t)CST_COUNT * npad, 0.0);

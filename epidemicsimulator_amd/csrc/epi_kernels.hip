@@ -1472,6 +1472,85 @@ hipError_t launch_world_unpack(const WorldIoArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Dense table preparation (see PrepareRowsArgs): one workgroup per row.  Every sum the reference forms left to
+// right (scaleRow's row sum, wRow.sum) is formed by one thread in that order; the element-wise products and
+// quotients are independent and spread over the threads.  The top-weights list is a bitonic sort in LDS.
+// ---------------------------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(256) void prepare_rows_kernel(const PrepareRowsArgs a) {
+    __shared__ double sh[NP];
+    __shared__ double sh_s;
+    const int n = a.n, tid = threadIdx.x, b = blockIdx.x;
+    const bool variant = a.travel != nullptr;
+    const int self = variant ? a.seed_idx : b;
+    const double* __restrict__ src = a.W + (size_t)self * n;
+    for (int j = tid; j < NP; j += 256) sh[j] = j < n ? src[j] : 0.0;
+    __syncthreads();
+    if (variant) {   // ToyConn.scaleRow: off-diagonals times factor, row sum capped at 0.2, diagonal 0
+        const double factor = a.travel[b];
+        for (int j = tid; j < n; j += 256)
+            if (j != self) sh[j] *= factor;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int j = 0; j < n; ++j)
+                if (j != self) s += sh[j];
+            sh_s = s;
+        }
+        __syncthreads();
+        const double s = sh_s, cap = fmin(0.2, s);
+        if (s > cap && s > 0) {
+            const double sc = cap / s;
+            for (int j = tid; j < n; j += 256)
+                if (j != self) sh[j] *= sc;
+        }
+        if (tid == 0) sh[self] = 0.0;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        sh[self] = 0.0;   // wRow: the origin's own entry is 0 (WorldToy.scala:113)
+        double sum = 0.0;
+        for (int j = 0; j < n; ++j) sum = (j == 0) ? sh[0] : sum + sh[j];
+        sh_s = sum;
+    }
+    __syncthreads();
+    const double sum = sh_s;
+    if (tid == 0) a.sumw[b] = fmax(0.0, sum);
+    for (int j = tid; j < NP; j += 256) {
+        const double qv = (j < n && sum > 0.0) ? sh[j] / sum : 0.0;
+        a.q[(size_t)b * a.npad + j] = qv;
+        sh[j] = qv;
+    }
+    __syncthreads();
+    // descending bitonic sort of the NP normalised weights (zeros of the padding sort last)
+    for (int k = 2; k <= NP; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < NP / 2; t += 256) {
+                const int lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+                const bool desc = ((lo & k) == 0);
+                const double x = sh[lo], y = sh[hi];
+                if (desc ? (x < y) : (x > y)) { sh[lo] = y; sh[hi] = x; }
+            }
+            __syncthreads();
+        }
+    for (int j = tid; j < kTopWeights; j += 256) a.qtop[(size_t)b * kTopWeights + j] = j < NP ? sh[j] : 0.0;
+}
+
+hipError_t launch_prepare_rows(const PrepareRowsArgs& a, hipStream_t s) {
+    if (a.n_rows <= 0) return hipSuccess;
+    const dim3 grid((unsigned)a.n_rows), block(256);
+    switch (a.npad) {
+        case 64: hipLaunchKernelGGL(prepare_rows_kernel<64>, grid, block, 0, s, a); break;
+        case 128: hipLaunchKernelGGL(prepare_rows_kernel<128>, grid, block, 0, s, a); break;
+        case 256: hipLaunchKernelGGL(prepare_rows_kernel<256>, grid, block, 0, s, a); break;
+        case 512: hipLaunchKernelGGL(prepare_rows_kernel<512>, grid, block, 0, s, a); break;
+        case 1024: hipLaunchKernelGGL(prepare_rows_kernel<1024>, grid, block, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // ToyConn.gravityMatrix (ToyConn.scala:22-47) with Geo.haversineKm (Geo.scala:72-79): one workgroup
 // per row i.  The threads fill the row tile by tile; one thread adds the tile up from left to right
 // (the reference's rowSum order) before all of them apply the row cap.  pow / sin / cos / atan2 are

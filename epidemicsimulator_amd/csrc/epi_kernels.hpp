@@ -208,6 +208,23 @@ struct GravityArgs {
     double* W;             // [n][n] out
 };
 
+// Table preparation of dense graphs on the device: per row the mobility loop's wRow (WorldToy.scala:113), its
+// left-to-right sum (:114), the normalised weights w / sumW (the first rounding of allocateInt, env.scala:244) and
+// the row's kTopWeights largest normalised weights in descending order.  Rows [0, n_rows) of W are prepared as they
+// are; with `travel` set, block k prepares ToyConn.scaleRow(W, seed_idx, travel[k]) (ToyConn.scala:58-70) of the
+// seed row instead -- the per-travel variants of the calibration sweep.
+struct PrepareRowsArgs {
+    int n, npad;
+    const double* W;        // [n][n] row-major
+    int n_rows;             // rows to prepare (plain mode) or travel scales (variant mode)
+    int seed_idx;           // variant mode: the row that is scaled
+    const double* travel;   // [n_rows] or NULL = plain mode
+    double* q;              // [n_rows][npad]
+    double* sumw;           // [n_rows] (plain mode: the caller passes a buffer of npad entries, zero beyond n)
+    double* qtop;           // [n_rows][kTopWeights]
+};
+hipError_t launch_prepare_rows(const PrepareRowsArgs& a, hipStream_t s);
+
 // Device view of the networks an epi_agents handle holds (epi_agents.hip).
 struct AgentsNetView {
     int device, n_agents;
