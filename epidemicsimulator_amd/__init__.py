@@ -221,6 +221,28 @@ class ToyConn:
         return W
 
     @staticmethod
+    def gravity_csr_device(countries, threshold: float, a=0.2, b=1.0, g=1.2, k=1e-6, cap_row=0.12, device: int = 0):
+        """gravity_matrix_device followed by to_csr, all on the GPU (epi_gravity_csr): the dense matrix is never
+        stored, only (rowptr, col, val) comes back.  For large synthetic graphs."""
+        n = len(countries)
+        pop = i32([c.pop for c in countries]); lat = f64([c.lat for c in countries]); lon = f64([c.lon for c in countries])
+        fl = None
+        names = [c.name for c in countries]
+        pairs = [(names.index(x), names.index(y), v) for (x, y), v in ToyConn.flight_mul.items() if x in names and y in names]
+        if pairs:
+            fl = np.ones((n, n))
+            for x, y, v in pairs:
+                fl[x, y] = v
+        flp = ptr(fl, C.c_double) if fl is not None else None
+        rowptr = np.zeros(n + 1, dtype=np.int32)
+        args = (n, ptr(pop, C.c_int32), ptr(lat, C.c_double), ptr(lon, C.c_double), flp, a, b, g, k, cap_row, threshold,
+                ptr(rowptr, C.c_int32))
+        check(lib().epi_gravity_csr(*args, None, None, device))
+        col = np.zeros(max(1, int(rowptr[-1])), dtype=np.int32); val = np.zeros(max(1, int(rowptr[-1])))
+        check(lib().epi_gravity_csr(*args, ptr(col, C.c_int32), ptr(val, C.c_double), device))
+        return rowptr, col[:rowptr[-1]], val[:rowptr[-1]]
+
+    @staticmethod
     def to_csr(W, threshold: float = 0.0):
         """Dense -> (rowptr, col, val) keeping the off-diagonal entries above `threshold`, columns ascending."""
         W = np.asarray(W, dtype=np.float64)

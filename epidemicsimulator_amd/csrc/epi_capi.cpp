@@ -1224,6 +1224,58 @@ EPI_API int32_t epi_gravity_matrix(int32_t n, const int32_t* pop, const double* 
     return EPI_OK;
 }
 
+EPI_API int32_t epi_gravity_csr(int32_t n, const int32_t* pop, const double* lat, const double* lon, const double* flight_mul,
+                                double a, double b, double g, double k, double cap_row, double threshold, int32_t* rowptr,
+                                int32_t* col, double* val, int32_t device) {
+    if (n < 0 || (n > 0 && (!pop || !lat || !lon)) || !rowptr) return fail(EPI_ERR_BAD_ARGUMENT, "epi_gravity_csr: null argument");
+    if ((col == nullptr) != (val == nullptr)) return fail(EPI_ERR_BAD_ARGUMENT, "epi_gravity_csr: col and val come together");
+    rowptr[0] = 0;
+    if (n == 0) return EPI_OK;
+    for (int i = 0; i < n; ++i)
+        if (pop[i] < 0 || !std::isfinite(lat[i]) || !std::isfinite(lon[i]))
+            return fail(EPI_ERR_BAD_ARGUMENT, "epi_gravity_csr: country %d: pop must be >= 0 and lat/lon finite", i);
+    if (!(threshold >= 0.0)) return fail(EPI_ERR_BAD_ARGUMENT, "epi_gravity_csr: threshold %g must be >= 0", threshold);
+    int32_t rc = use_device(device);
+    if (rc) return rc;
+    DevBuf dpop, dlat, dlon, dfl, dscale, dcnt, drp, dcol, dval;
+    HIP_TRY(dpop.upload(std::vector<int32_t>(pop, pop + n)));
+    HIP_TRY(dlat.upload(std::vector<double>(lat, lat + n)));
+    HIP_TRY(dlon.upload(std::vector<double>(lon, lon + n)));
+    if (flight_mul) {
+        HIP_TRY(dfl.ensure((size_t)n * n * sizeof(double)));
+        HIP_TRY(hipMemcpy(dfl.p, flight_mul, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(dscale.ensure((size_t)n * sizeof(double)));
+    HIP_TRY(dcnt.ensure((size_t)n * sizeof(int32_t)));
+    GravityCsrArgs ca{};
+    ca.g.n = n; ca.g.pop = dpop.as<int32_t>(); ca.g.lat = dlat.as<double>(); ca.g.lon = dlon.as<double>();
+    ca.g.flight = flight_mul ? dfl.as<double>() : nullptr;
+    ca.g.a = a; ca.g.b = b; ca.g.g = g; ca.g.k = k; ca.g.cap_row = cap_row; ca.g.W = nullptr;
+    ca.threshold = threshold;
+    ca.scale = dscale.as<double>(); ca.counts = dcnt.as<int32_t>();
+    ca.mode = 0;
+    HIP_TRY(launch_gravity_csr(ca, nullptr));
+    ca.mode = 1;
+    HIP_TRY(launch_gravity_csr(ca, nullptr));
+    std::vector<int32_t> cnt((size_t)n);
+    HIP_TRY(hipMemcpy(cnt.data(), dcnt.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        total += cnt[i];
+        if (total > 2147483647LL) return fail(EPI_ERR_UNSUPPORTED, "epi_gravity_csr: more than 2^31 - 1 stored entries");
+        rowptr[i + 1] = (int32_t)total;
+    }
+    if (!col || total == 0) return EPI_OK;   // first call: the caller sizes col / val from rowptr[n]
+    HIP_TRY(drp.upload(std::vector<int32_t>(rowptr, rowptr + n + 1)));
+    HIP_TRY(dcol.ensure((size_t)total * sizeof(int32_t)));
+    HIP_TRY(dval.ensure((size_t)total * sizeof(double)));
+    ca.mode = 2; ca.rowptr = drp.as<int32_t>(); ca.col = dcol.as<int32_t>(); ca.val = dval.as<double>();
+    HIP_TRY(launch_gravity_csr(ca, nullptr));
+    HIP_TRY(hipMemcpy(col, dcol.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(val, dval.p, (size_t)total * sizeof(double), hipMemcpyDeviceToHost));
+    return EPI_OK;
+}
+
 // ================================================================================================
 // batched worlds
 // ================================================================================================

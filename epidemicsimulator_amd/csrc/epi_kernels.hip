@@ -1568,6 +1568,15 @@ __device__ __forceinline__ double haversine_km(double lat1, double lon1, double 
     return 6371.0 * c;
 }
 
+// Raw entry (i, j) of the gravity matrix before the row cap (ToyConn.scala:28-38), one expression shared by the
+// dense and the sparse builders so that both produce the same doubles.
+__device__ __forceinline__ double gravity_entry(const GravityArgs& a, int i, int j, double lat_i, double lon_i, double pa) {
+    if (j == i) return 0.0;
+    const double d = fmax(300.0, haversine_km(lat_i, lon_i, a.lat[j], a.lon[j]));
+    const double f = a.flight ? a.flight[(size_t)i * a.n + j] : 1.0;
+    return a.k * pa * pow((double)a.pop[j], a.b) * f / pow(d, a.g);
+}
+
 __global__ __launch_bounds__(256) void gravity_rows_kernel(const GravityArgs a) {
     __shared__ double tile[kGravityTile];
     __shared__ double sh_sum;
@@ -1580,12 +1589,7 @@ __global__ __launch_bounds__(256) void gravity_rows_kernel(const GravityArgs a) 
         const int cnt = min(kGravityTile, n - j0);
         for (int jj = threadIdx.x; jj < cnt; jj += blockDim.x) {
             const int j = j0 + jj;
-            double w = 0.0;
-            if (j != i) {
-                const double d = fmax(300.0, haversine_km(lat_i, lon_i, a.lat[j], a.lon[j]));
-                const double f = a.flight ? a.flight[(size_t)i * n + j] : 1.0;
-                w = a.k * pa * pow((double)a.pop[j], a.b) * f / pow(d, a.g);
-            }
+            const double w = gravity_entry(a, i, j, lat_i, lon_i, pa);
             tile[jj] = w;
             row[j] = w;
         }
@@ -1604,6 +1608,63 @@ __global__ __launch_bounds__(256) void gravity_rows_kernel(const GravityArgs a) 
         for (int j = threadIdx.x; j < n; j += blockDim.x)
             if (j != i) row[j] *= scale;
     }
+}
+
+__global__ __launch_bounds__(256) void gravity_csr_kernel(const GravityCsrArgs c) {
+    __shared__ double tile[kGravityTile];
+    __shared__ double sh_sum;
+    __shared__ int sh_cnt[4], sh_base;
+    const GravityArgs& a = c.g;
+    const int i = blockIdx.x, n = a.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double lat_i = a.lat[i], lon_i = a.lon[i];
+    const double pa = pow((double)a.pop[i], a.a);
+    if (c.mode == 0) {   // row sum, left to right (ToyConn.scala:39), tile by tile
+        if (tid == 0) sh_sum = 0.0;
+        for (int j0 = 0; j0 < n; j0 += kGravityTile) {
+            const int cnt = min(kGravityTile, n - j0);
+            for (int jj = tid; jj < cnt; jj += 256) tile[jj] = gravity_entry(a, i, j0 + jj, lat_i, lon_i, pa);
+            __syncthreads();
+            if (tid == 0) {
+                double s = sh_sum;
+                for (int jj = 0; jj < cnt; ++jj)
+                    if (j0 + jj != i) s += tile[jj];
+                sh_sum = s;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) c.scale[i] = sh_sum > 0 ? fmin(1.0, a.cap_row / sh_sum) : 1.0;
+        return;
+    }
+    const double scale = c.scale[i];
+    if (tid == 0) sh_base = 0;
+    __syncthreads();
+    // columns in runs of 256, in order: every stored entry's position is the number of stored entries before it
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + tid;
+        double w = 0.0;
+        if (j < n && j != i) w = gravity_entry(a, i, j, lat_i, lon_i, pa) * scale;
+        const bool keep = j < n && j != i && w > c.threshold;
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) sh_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = sh_base;
+        for (int k = 0; k < wave; ++k) before += sh_cnt[k];
+        if (keep && c.mode == 2) {
+            const size_t at = (size_t)c.rowptr[i] + before + (int)lanes_below(m);
+            c.col[at] = j;
+            c.val[at] = w;
+        }
+        __syncthreads();
+        if (tid == 0) sh_base += sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
+        __syncthreads();
+    }
+    if (c.mode == 1 && tid == 0) c.counts[i] = sh_base;
+}
+
+hipError_t launch_gravity_csr(const GravityCsrArgs& a, hipStream_t s) {
+    if (a.g.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gravity_csr_kernel, dim3((unsigned)a.g.n), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_gravity(const GravityArgs& a, hipStream_t s) {

@@ -237,6 +237,19 @@ struct epi_agents;
 namespace epi {
 int32_t agents_net_view(epi_agents* g, AgentsNetView* v);
 
+// The same matrix cut to a sparse graph on the device: entries W_ij > threshold (i != j), columns ascending.
+// mode 0: scale[i] = the row's cap factor min(1, cap_row / rowSum) (1 for an empty row); mode 1: counts[i] = stored
+// entries of row i; mode 2: col / val filled from rowptr.
+struct GravityCsrArgs {
+    GravityArgs g;          // g.W unused
+    double threshold;
+    int mode;
+    double* scale;          // [n]
+    int32_t* counts;        // [n]
+    const int32_t* rowptr;  // [n+1]
+    int32_t* col; double* val;
+};
+hipError_t launch_gravity_csr(const GravityCsrArgs& a, hipStream_t s);
 hipError_t launch_gravity(const GravityArgs& a, hipStream_t s);
 hipError_t launch_world_pack(const WorldIoArgs& a, hipStream_t s);
 hipError_t launch_world_unpack(const WorldIoArgs& a, hipStream_t s);

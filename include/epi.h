@@ -109,6 +109,15 @@ int32_t epi_gravity_matrix(int32_t n, const int32_t *pop, const double *lat, con
                            const double *flight_mul, double a, double b, double g, double k, double cap_row,
                            double *W, int32_t device);
 
+/* The same matrix cut to a sparse graph on the device -- the entries W_ij > threshold (i != j), columns ascending
+ * inside a row -- without the dense matrix ever being stored: rows are formed and compacted in LDS, only the CSR
+ * triple reaches the host (a 20,000-patch graph is 3.2 GB dense, a few MB sparse).  Call it with col = val = NULL to
+ * get rowptr[n+1] (rowptr[n] = number of stored entries), then again with arrays of that size.  Same doubles as
+ * epi_gravity_matrix followed by a host-side cut. */
+int32_t epi_gravity_csr(int32_t n, const int32_t *pop, const double *lat, const double *lon, const double *flight_mul,
+                        double a, double b, double g, double k, double cap_row, double threshold, int32_t *rowptr,
+                        int32_t *col, double *val, int32_t device);
+
 /* ---- JVM-compatible streams (scala.util.Random at env.scala:42,91; DDQNAgent.scala:14-32;
  *      MLP.scala:5-9) ------------------------------------------------------------------------- */
 int32_t epi_java_gaussians(int64_t seed, int32_t n, double *out);

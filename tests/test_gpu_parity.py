@@ -884,3 +884,29 @@ def test_gravity_matrix_on_device(epi, n):
     if n == 300:  # the device-built matrix is a valid engine input: sparse form of it runs and conserves mass
         rp, col, val = epi.ToyConn.to_csr(got, threshold=np.quantile(got, 0.9))
         assert rp[-1] == len(col) == len(val) and (np.diff(rp) > 0).all()
+
+
+@pytest.mark.parametrize("n", [6, 300, 5000])
+def test_gravity_csr_on_device(epi, n):
+    """epi_gravity_csr -- the matrix formed and cut to a sparse graph on the device, rows compacted in column order --
+    against the dense device matrix cut on the host: same structure, same doubles.  n = 5000 spans two row tiles."""
+    from epidemicsimulator_amd import synth
+    countries = list(epi.ToyConn.C) if n == 6 else synth.make_countries(n, 13)[0]
+    dense = epi.ToyConn.gravity_matrix_device(countries)
+    for thr in (0.0, float(np.quantile(dense, 0.97)), 1.0):
+        want = epi.ToyConn.to_csr(dense, thr)
+        got = epi.ToyConn.gravity_csr_device(countries, thr)
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g, w)
+    # a sparse world built from it steps and conserves mass (rows that lost every entry export nothing)
+    if n == 5000:
+        rp, col, val = epi.ToyConn.gravity_csr_device(countries, float(np.quantile(dense, 0.997)))
+        assert 5 < rp[-1] / n < 40
+        base = epi.State(0, 0, 0, 0, 0, 10_000, 0, 50, 1)
+        w = epi.WorldToy(epi.HyperParams(), base, 0, (rp, col, val), validate=True, countries=countries, learning=False)
+        rng = np.random.default_rng(1)
+        total = sum(c.pop for c in countries)
+        for _ in range(4):
+            st, _ = w.step_arrays(rng.integers(0, 8, (1, n)), rng.normal(size=(1, n)), 50)
+            assert int((st["s"] + st["i"] + st["r"] + st["d"] + st["v"]).sum()) == total
+        w.close()
