@@ -420,6 +420,11 @@ class Agents:
         check(lib().epi_agents_observe(self._h, idp, C.c_int32(k), s, ptr(a, C.c_int32), ptr(r, C.c_double), s2,
                                        ptr(d, C.c_uint8)))
 
+    def observe_world(self, world: "WorldToy") -> None:
+        """DDQNAgent.observe for the world's last step, filed on the device (epi_agents_observe_world): agent c gets
+        the transition of country c of every instance; no state crosses the bus."""
+        check(lib().epi_agents_observe_world(self._h, world._h))
+
     def replay_size(self) -> np.ndarray:
         out = np.zeros(self.n, dtype=np.int32)
         check(lib().epi_agents_replay_size(self._h, ptr(out, C.c_int32)))
@@ -656,8 +661,9 @@ class WorldToy:
                  make_env: Callable[[], EpidemicEnv] = lambda: EpidemicEnv(),
                  make_env_for: Optional[Callable[[str, int], EpidemicEnv]] = None, validate: bool = False,
                  countries: Optional[Sequence[Geo.Country]] = None, batch: int = 1, device: int = 0,
-                 country_hyper_params: Optional[dict] = None, learning: bool = True):
+                 country_hyper_params: Optional[dict] = None, learning: bool = True, device_transitions: bool = True):
         self.hp, self.base, self.seed_idx, self.validate, self.batch = hp, base, seed_idx, validate, batch
+        self.device_transitions = device_transitions   # file the agents' transitions from the device planes (no round trip)
         self._device = device
         self.learning = bool(learning) and batch == 1
         self.g_step = 0
@@ -821,6 +827,8 @@ class WorldToy:
             self._pool = Agents([nd.hyper_params for nd in self.nodes], max_grad_accum=4, device=self._device)
             for nd in self.nodes:
                 nd.agent = DDQNAgent(nd.hyper_params, pool=self._pool, index=nd.idx)
+            if self.device_transitions:
+                check(lib().epi_world_keep_transitions(self._h, C.c_int32(1)))
 
     # WorldToy.scala:157-162
     LEARNING_INTENSITY = {"India": 2, "Japan": 1, "Germany": 1}
@@ -848,6 +856,15 @@ class WorldToy:
             for k, a in zip(greedy_ids, g):
                 acts[k] = int(a)
         states, r = self.step_actions([acts], None, t_max)
+        if self.device_transitions:
+            self._pool.observe_world(self)     # :99, from the planes the world kept on the device
+        else:
+            self._observe_from_host(before, acts, states, r)
+        self.g_step += 1
+        return self._learn_due(states, r)
+
+    def _observe_from_host(self, before, acts, states, r):
+        """agent.observe (:99) with the transitions rebuilt on the host from the returned states and flows."""
         ms, mi = self.last_flows()
         trs = []
         for k, nd in enumerate(self.nodes):
@@ -859,7 +876,9 @@ class WorldToy:
             done = (s2.t >= s2.t_max) or (s2.i / nn < 1e-5) or (s2.d / nn > 0.02)   # env.scala:137
             trs.append(Transition(before[k], acts[k], float(r[0][k]), s2, done))
         self._pool.observe(trs)
-        self.g_step += 1
+
+    def _learn_due(self, states, r):
+        """The per-country learning schedule of WorldToy.scala:147-167."""
         sizes = self._pool.replay_size()
         due = [nd for nd in self.nodes
                if self.g_step - nd.last_learn_step >= nd.hyper_params.learn_every

@@ -85,10 +85,10 @@ EXPORTED_SYMBOLS = [
     "epi_env_step_batch", "epi_scale_row", "epi_gravity_matrix", "epi_gravity_csr", "epi_java_gaussians", "epi_agent_actions", "epi_mlp_init",
     "epi_mlp_greedy_batch", "epi_grid_create", "epi_grid_run", "epi_grid_run_strided", "epi_grid_run_noalloc", "epi_grid_status", "epi_grid_destroy",
     "epi_grid_argmin", "epi_calibrate_grid", "epi_grid_multi_create", "epi_grid_multi_run", "epi_grid_multi_ranks",
-    "epi_grid_multi_destroy", "epi_calibrate_grid_multi", "epi_grid_set_timing", "epi_grid_kernel_time", "epi_world_create", "epi_world_step", "epi_world_step_greedy", "epi_world_rollout_greedy",
+    "epi_grid_multi_destroy", "epi_calibrate_grid_multi", "epi_grid_set_timing", "epi_grid_kernel_time", "epi_world_create", "epi_world_step", "epi_world_step_greedy", "epi_world_rollout_greedy", "epi_world_keep_transitions",
     "epi_world_set_mlp", "epi_world_get_states", "epi_world_set_states", "epi_world_reset", "epi_world_last_flows",
     "epi_world_set_timing", "epi_world_kernel_time", "epi_world_result_buffers", "epi_world_destroy",
-    "epi_agents_create", "epi_agents_destroy", "epi_agents_observe", "epi_agents_replay_size", "epi_agents_sample",
+    "epi_agents_create", "epi_agents_destroy", "epi_agents_observe", "epi_agents_observe_world", "epi_agents_replay_size", "epi_agents_sample",
     "epi_agents_learn", "epi_agents_q_values", "epi_agents_get_weights", "epi_agents_set_weights",
     "epi_agents_set_timing", "epi_agents_kernel_time",
 ]
@@ -139,6 +139,8 @@ def lib():
         L.epi_agents_create.argtypes = [C.c_int32, C.POINTER(LearnHyper), C.c_int32]
         L.epi_agents_destroy.argtypes = [C.c_void_p]
         L.epi_agents_observe.argtypes = [C.c_void_p, _PI, C.c_int32, C.POINTER(CState), _PI, _PD, C.POINTER(CState), _PU8]
+        L.epi_agents_observe_world.argtypes = [C.c_void_p, C.c_void_p]
+        L.epi_world_keep_transitions.argtypes = [C.c_void_p, C.c_int32]
         L.epi_agents_replay_size.argtypes = [C.c_void_p, _PI]
         L.epi_agents_sample.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _PI, _PI]
         L.epi_agents_learn.argtypes = [C.c_void_p, _PI, C.c_int32, _PI, _PI, C.POINTER(C.c_int64), _PD, _PD]

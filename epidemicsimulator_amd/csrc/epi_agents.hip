@@ -428,6 +428,42 @@ __global__ void __launch_bounds__(64) agents_push_kernel(RingRec* ring, const Ri
     if (k < count) ring[dst[k]] = staged[k];
 }
 
+// DDQNAgent.observe for the last step of a world, filed from the world's own device planes: agent c receives, for
+// every instance e, Transition(s, a, r, s2, done) with s = the state before the step, s2 = the state right after
+// env.step (WorldToy.scala:90,99: before the mobility flows, env.step's own clock), done as env.scala:137.
+__global__ __launch_bounds__(64) void agents_file_kernel(RingRec* ring, const long long* dst, WorldTransitionView v) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;   // k = c * batch + e
+    if (k >= v.n * v.batch) return;
+    const int c = k / v.batch, e = k - c * v.batch;
+    const size_t idx = (size_t)e * v.npad + c;
+    RingRec rec;
+    const double tm = (double)(v.t_max > 1 ? v.t_max : 1);
+    {
+        const double s = (double)v.prev_st[0 * v.plane + idx], i = (double)v.prev_st[1 * v.plane + idx];
+        const double r = (double)v.prev_st[2 * v.plane + idx], d = (double)v.prev_st[3 * v.plane + idx];
+        const double vv = (double)v.prev_st[4 * v.plane + idx];
+        const double N = fmax(1.0, s + i + r + d);
+        rec.fs[0] = s / N; rec.fs[1] = i / N; rec.fs[2] = r / N; rec.fs[3] = d / N; rec.fs[4] = vv / N;
+        rec.fs[5] = i / fmax(1.0, v.prev_cap[idx]);
+        rec.fs[6] = (double)v.prev_tcur[idx] / tm;
+        rec.fs[7] = 0.0;
+    }
+    {
+        const double s = (double)v.loc_s[idx], i = (double)v.loc_i[idx];
+        const double r = (double)v.st[2 * v.plane + idx], d = (double)v.st[3 * v.plane + idx], vv = (double)v.st[4 * v.plane + idx];
+        const int32_t t2 = (int32_t)((uint32_t)v.prev_tcur[idx] + 1u);   // env.scala:132
+        const double n4 = s + i + r + d, N = fmax(1.0, n4);
+        rec.fs2[0] = s / N; rec.fs2[1] = i / N; rec.fs2[2] = r / N; rec.fs2[3] = d / N; rec.fs2[4] = vv / N;
+        rec.fs2[5] = i / fmax(1.0, v.cap[idx]);
+        rec.fs2[6] = (double)t2 / tm;
+        rec.fs2[7] = 0.0;
+        rec.done = (t2 >= v.t_max || i / N < 1e-5 || d / N > 0.02) ? 1 : 0;   // env.scala:137
+    }
+    rec.r = v.reward[idx];
+    rec.a = (int32_t)v.act[idx];
+    ring[dst[k]] = rec;
+}
+
 // State.features (env.scala:26-30)
 void features(const epi_state& s, double* f) {
     const double n = s.s + s.i + s.r + s.d;
@@ -470,7 +506,7 @@ struct epi_agents {
     std::vector<Replay> replay;
     std::vector<double> ema;
     DevBuf nets, hyper, H1, H2, Q, DZ2, DZ1, ERR, X0d, ACTd, ring, ring_off;
-    PinBuf slot_agent, slot_rows, X, idx, loss, push_rec, push_dst;
+    PinBuf slot_agent, slot_rows, X, idx, loss, push_rec, push_dst, file_dst;
     std::vector<long long> h_ring_off;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -611,6 +647,25 @@ EPI_API int32_t epi_agents_observe(epi_agents* g, const int32_t* ids, int32_t co
                        g->push_rec.on_device<RingRec>(), g->push_dst.on_device<long long>(), count);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(g->stream));  // the staging arrays are free again
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_agents_observe_world(epi_agents* g, epi_world* w) {
+    if (!g || !w) return fail(EPI_ERR_BAD_ARGUMENT, "agents_observe_world: null argument");
+    WorldTransitionView v{};
+    if (int32_t rc = world_transition_view(w, &v)) return rc;
+    if (v.device != g->device) return fail(EPI_ERR_BAD_ARGUMENT, "agents_observe_world: the world lives on device %d, the agents on device %d", v.device, g->device);
+    if (v.n > g->n) return fail(EPI_ERR_BAD_ARGUMENT, "agents_observe_world: %d countries, %d agents (one agent per node, WorldToy.scala:50)", v.n, g->n);
+    if (int32_t rc = use_device(g->device)) return rc;
+    const size_t count = (size_t)v.n * v.batch;
+    HIP_TRY(g->file_dst.ensure(count * sizeof(long long)));
+    long long* dst = g->file_dst.as<long long>();
+    for (int c = 0; c < v.n; ++c)
+        for (int e = 0; e < v.batch; ++e) dst[(size_t)c * v.batch + e] = g->h_ring_off[c] + g->replay[c].push();
+    hipLaunchKernelGGL(agents_file_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, g->stream, g->ring.as<RingRec>(),
+                       g->file_dst.on_device<long long>(), v);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g->stream));  // the staging array is free again
     return EPI_OK;
 }
 

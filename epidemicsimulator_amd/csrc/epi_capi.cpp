@@ -504,6 +504,9 @@ struct epi_world {
     EpisodeBuffers work;
     DevBuf act_dev, gauss_dev, reward_dev, flow_s, flow_i, q_tmp;
     DevBuf noise_tab, series_dev, arr_out, peak_out;   // greedy rollouts: per-step noise table, I-series, compact metrics
+    // transitions kept for epi_agents_observe_world: the states before the last step and S, I right after env.step
+    bool keep_tr = false, have_tr = false;
+    DevBuf prev_st, prev_cap, prev_tcur, loc_s, loc_i;
     // compact [batch][n] images of the caller's arrays in page-locked, device-mapped host memory
     PinBuf pin_act, pin_gauss, pin_states, pin_rewards, pin_actions, pin_err;
 
@@ -1474,7 +1477,12 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
     }
     // Small worlds (the toy world of the batched DDQN rollout): the episode kernel reads the compact inputs and writes
     // the compact results itself -- one launch per step instead of pack + episode + unpack.
-    const bool fused = !greedy && !w->graph.sparse && n <= 16 && npad == 64;
+    const bool fused = !greedy && !w->graph.sparse && n <= 16 && npad == 64 && !w->keep_tr;
+    if (w->keep_tr) {   // the Transition's `s` (WorldToy.scala:99): the states as they are before this step
+        HIP_TRY(hipMemcpyAsync(w->prev_st.p, w->work.st.p, cells * 5 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(w->prev_cap.p, w->work.cap.p, cells * sizeof(double), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(w->prev_tcur.p, w->work.tcur.p, cells * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    }
     if (!fused) HIP_TRY(launch_world_pack(io, s));
     if (greedy) {
         MlpArgs ma{};
@@ -1503,6 +1511,7 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
     ea.arrival = w->work.arrival.as<int32_t>(); ea.peak = w->work.peak.as<int32_t>(); ea.err = w->work.err.as<int32_t>();
     ea.rwd = w->rwd.as<RewardConsts>(); ea.reward_out = w->reward_dev.as<double>();
     ea.flow_s = w->flow_s.as<int32_t>(); ea.flow_i = w->flow_i.as<int32_t>();
+    if (w->keep_tr) { ea.loc_s = w->loc_s.as<int32_t>(); ea.loc_i = w->loc_i.as<int32_t>(); }
     if (fused) {
         ea.io_actions = io.actions; ea.io_gauss = io.gauss; ea.io_gauss_row = io.gauss_row;
         ea.io_states = out_states ? w->pin_states.on_device<epi_state>() : nullptr;
@@ -1530,6 +1539,7 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
         w->kernel_country_steps += (long long)B * n;
     }
     w->have_flows = true;
+    w->have_tr = w->keep_tr;
     if (out_states && out_states != w->pin_states.p) std::memcpy(out_states, w->pin_states.p, compact * sizeof(epi_state));
     if (out_rewards && out_rewards != w->pin_rewards.p) std::memcpy(out_rewards, w->pin_rewards.p, compact * sizeof(double));
     if (out_actions && out_actions != w->pin_actions.p) std::memcpy(out_actions, w->pin_actions.p, compact * sizeof(int32_t));
@@ -1649,6 +1659,37 @@ EPI_API int32_t epi_world_rollout_greedy(epi_world* w, epi_agents* agents, int32
     }
     return collect_errors(w->work.err.as<int32_t>(), B, 0);
 }
+
+EPI_API int32_t epi_world_keep_transitions(epi_world* w, int32_t on) {
+    if (!w) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_keep_transitions: null handle");
+    HIP_TRY(hipSetDevice(w->device));
+    if (on) {
+        const size_t cells = (size_t)w->batch * w->npad;
+        HIP_TRY(w->prev_st.ensure(cells * 5 * sizeof(int32_t)));
+        HIP_TRY(w->prev_cap.ensure(cells * sizeof(double)));
+        HIP_TRY(w->prev_tcur.ensure(cells * sizeof(int32_t)));
+        HIP_TRY(w->loc_s.ensure(cells * sizeof(int32_t)));
+        HIP_TRY(w->loc_i.ensure(cells * sizeof(int32_t)));
+    }
+    w->keep_tr = on != 0;
+    w->have_tr = false;
+    return EPI_OK;
+}
+
+namespace epi {
+int32_t world_transition_view(epi_world* w, WorldTransitionView* v) {
+    if (!w || !v) return fail(EPI_ERR_BAD_ARGUMENT, "world_transition_view: null argument");
+    if (!w->keep_tr || !w->have_tr)
+        return fail(EPI_ERR_BAD_ARGUMENT, "the world holds no transition: call epi_world_keep_transitions(w, 1) and step it first");
+    v->device = w->device; v->n = w->n; v->npad = w->npad; v->batch = w->batch; v->t_max = w->base.t_max;
+    v->plane = (size_t)w->batch * w->npad;
+    v->prev_st = w->prev_st.as<int32_t>(); v->prev_cap = w->prev_cap.as<double>(); v->prev_tcur = w->prev_tcur.as<int32_t>();
+    v->loc_s = w->loc_s.as<int32_t>(); v->loc_i = w->loc_i.as<int32_t>();
+    v->st = w->work.st.as<int32_t>(); v->cap = w->work.cap.as<double>();
+    v->reward = w->reward_dev.as<double>(); v->act = w->act_dev.as<int8_t>();
+    return EPI_OK;
+}
+}  // namespace epi
 
 EPI_API int32_t epi_world_set_timing(epi_world* w, int32_t on) {
     if (!w) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_set_timing: null handle");

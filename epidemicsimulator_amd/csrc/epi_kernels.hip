@@ -138,6 +138,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(W > R ? 
             if (a.rwd) a.reward_out[eoff + tid] = reward_of(a.rwd[tid], (double)i0, (double)d0, o, act);
             sh_s[tid] = o.s; sh_i[tid] = o.i; sh_r[tid] = o.r; sh_d[tid] = o.d; sh_v[tid] = o.v;
             sh_cap[tid] = o.cap;
+            if (a.loc_s) { a.loc_s[eoff + tid] = o.s; a.loc_i[eoff + tid] = o.i; }
             tcur += 1;  // env.scala:132
             eS = export_count(max(0, o.s), my_sumw);
             eI = export_count(max(0, o.i), my_sumw);
@@ -715,6 +716,7 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 if (a.rwd) a.reward_out[eoff + c] = reward_of(a.rwd[c], (double)i0, (double)d0, o, act);
                 st_s[c] = o.s; st_i[c] = o.i; st_r[c] = o.r; st_d[c] = o.d; st_v[c] = o.v;
                 a.cap[eoff + c] = o.cap;
+                if (a.loc_s) { a.loc_s[eoff + c] = o.s; a.loc_i[eoff + c] = o.i; }
                 a.tcur[eoff + c] = tc + 1;
                 const int32_t eS = export_count(max(0, o.s), p.sw), eI = export_count(max(0, o.i), p.sw);
                 expS[c] = eS;
@@ -950,6 +952,7 @@ __global__ __launch_bounds__(64) void episode_tiny_kernel(const EpisodeArgs a) {
             }
             s = o.s; i = o.i; r = o.r; d = o.d; v = o.v;
             cap = o.cap;
+            if (a.loc_s) { a.loc_s[eoff + c] = s; a.loc_i[eoff + c] = i; }
             tcur += 1;  // env.scala:132
             eS = export_count(max(0, s), my_sumw);
             eI = export_count(max(0, i), my_sumw);

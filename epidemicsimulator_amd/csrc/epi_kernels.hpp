@@ -94,6 +94,8 @@ struct EpisodeArgs {
     double* io_rewards;          // [count][n] or NULL
     int32_t* io_err;             // [count][4] copy of the error table
     int32_t io_t_max, io_seed;
+    int32_t* loc_s;          // optional [count][npad]: S and I right after env.step, before the mobility flows are
+    int32_t* loc_i;          // applied -- the s2 of the Transition the agents observe (WorldToy.scala:90,99)
     double* series_i;        // optional [.][count][n]: I of every country after step t at index t - series_t0
     int series_t0;           // (the series the trainer's evaluation collects, MutliTrainer.scala:139)
 };
@@ -224,6 +226,22 @@ struct PrepareRowsArgs {
     double* qtop;           // [n_rows][kTopWeights]
 };
 hipError_t launch_prepare_rows(const PrepareRowsArgs& a, hipStream_t s);
+
+// What DDQNAgent.observe needs of the last world step, as the world keeps it on the device (epi_capi.cpp): the
+// states before the step, S and I right after env.step, the current planes (R, D, V and hospCap are not touched by
+// mobility), rewards and clamped action ids.
+struct WorldTransitionView {
+    int device, n, npad, batch, t_max;
+    size_t plane;                                                    // batch * npad
+    const int32_t* prev_st; const double* prev_cap; const int32_t* prev_tcur;
+    const int32_t* loc_s; const int32_t* loc_i;
+    const int32_t* st; const double* cap;
+    const double* reward; const int8_t* act;
+};
+}  // namespace epi
+struct epi_world;
+namespace epi {
+int32_t world_transition_view(epi_world* w, WorldTransitionView* v);
 
 // Device view of the networks an epi_agents handle holds (epi_agents.hip).
 struct AgentsNetView {

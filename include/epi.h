@@ -273,6 +273,9 @@ int32_t epi_world_step_greedy(epi_world *w, const double *gauss, int32_t t_max, 
  * states.  snapshotStates / resetToInitial / restoreStates around it are epi_world_get_states / _reset / _set_states. */
 int32_t epi_world_rollout_greedy(epi_world *w, epi_agents *agents, int32_t steps, int32_t t_max, double *i_series,
                                  int32_t *arrival, double *peak, epi_state *out_states);
+/* Makes the world keep, on the device, what DDQNAgent.observe needs of every following step (the states before it
+ * and S, I right after env.step) for epi_agents_observe_world.  Off by default: it costs three plane copies a step. */
+int32_t epi_world_keep_transitions(epi_world *w, int32_t on);
 int32_t epi_world_set_mlp(epi_world *w, int32_t hidden, const double *W1, const double *b1, const double *W2,
                           const double *b2, const double *W3, const double *b3, double clip_q);
 int32_t epi_world_get_states(epi_world *w, epi_state *out);       /* snapshotStates :75 */
@@ -304,6 +307,12 @@ int32_t epi_agents_destroy(epi_agents *g);
  * agents 0..count-1.  The buffers keep State.features of s and s2, the only parts learn() reads. */
 int32_t epi_agents_observe(epi_agents *g, const int32_t *ids, int32_t count, const epi_state *s, const int32_t *a,
                            const double *r, const epi_state *s2, const uint8_t *done);
+/* The same for the last step of a world, without the states crossing the bus: agent c observes, for every instance
+ * of the world, Transition(s, a, r, s2, done) with s = the state before the step, a = the action taken, r = the
+ * reward, s2 = the state env.step returned (WorldToy.scala:90,99: before the mobility flows, with env.step's own
+ * clock) and done as env.scala:137 -- computed from the planes the world keeps on the device once
+ * epi_world_keep_transitions(w, 1) was called.  Instances are filed in order 0 .. batch-1.  Same device. */
+int32_t epi_agents_observe_world(epi_agents *g, epi_world *w);
 /* DDQNAgent.replaySize (:69) of every agent: sizes[n_agents]. */
 int32_t epi_agents_replay_size(epi_agents *g, int32_t *sizes);
 /* ReplayBuffer.sample (ReplayBuffer.scala:21-22): buffer positions of rnd.shuffle(buf).take(n); advances the

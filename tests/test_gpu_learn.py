@@ -252,3 +252,62 @@ def test_empty_calls_are_no_ops(epi):
         agents.observe([epi.Transition(epi.State(1, 0, 0, 0, 0, 1, 0, 1, 1), 9, 0.0, epi.State(1, 0, 0, 0, 0, 1, 1, 1, 1), False)], [0])
     with pytest.raises(epi.EpiError):
         agents.q_values([epi.State(1, 0, 0, 0, 0, 1, 0, 1, 1)] * 2, [1, 1])   # an agent listed twice
+
+
+def test_transitions_filed_on_the_device(epi):
+    """epi_agents_observe_world (the transitions of WorldToy.scala:97-100 built from the world's device planes)
+    against epi_agents_observe fed with transitions rebuilt on the host: (1) the whole training loop of a single
+    world, both ways, losses and networks equal; (2) a batch of three instances: every agent receives its country's
+    transition of every instance, in instance order."""
+    hp = epi.HyperParams(hidden=16, batch_size=3, learn_every=2, epsilon_decay_steps=25, epsilon_end=0.2, target_update_every=3,
+                         replay_capacity=25, lr=5e-3)
+    base = epi.State(1e6, 0, 0, 0, 0, 10000.0, 0, 40, 1)     # tMax 40: the clock saturates and `done` fires inside the run
+    wa = epi.WorldToy(hp, base, validate=True, device_transitions=True)
+    wb = epi.WorldToy(hp, base, validate=True, device_transitions=False)
+    for step in range(50):
+        oa, ob = wa.step_one(40), wb.step_one(40)
+        assert [(s.s, s.i, s.r, s.d, s.v, s.t) for _, s, _ in oa] == [(s.s, s.i, s.r, s.d, s.v, s.t) for _, s, _ in ob]
+        assert wa.last_losses == wb.last_losses, step
+    for k in range(6):
+        for tgt in (False, True):
+            for x, y in zip(wa._pool.weights(k, tgt), wb._pool.weights(k, tgt)):
+                np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(wa._pool.replay_size(), wb._pool.replay_size())
+    wa.close(); wb.close()
+
+    # (2) batch of three worlds
+    import ctypes as C
+    B, n = 3, 6
+    w = epi.WorldToy(hp, base, validate=True, batch=B, learning=False)
+    epi.check(epi.lib().epi_world_keep_transitions(w._h, C.c_int32(1)))
+    pa = epi.Agents([hp] * n, max_grad_accum=2)
+    pb = epi.Agents([hp] * n, max_grad_accum=2)
+    rng = np.random.default_rng(8)
+    prev = w._get_states()
+    for step in range(9):
+        acts = rng.integers(-1, 10, (B, n))                 # out-of-range ids are clamped before they are stored
+        gauss = rng.normal(size=(B, n))
+        states, rewards = w.step_actions(acts, gauss, 40)
+        ms, mi = w.last_flows()
+        pa.observe_world(w)
+        for c in range(n):
+            for e in range(B):
+                s3 = states[e][c]
+                s2 = s3.copy(s=s3.s - float(ms[e][c]), i=s3.i - float(mi[e][c]), t=prev[e][c].t + 1)
+                nn = max(1.0, s2.n)
+                done = (s2.t >= s2.t_max) or (s2.i / nn < 1e-5) or (s2.d / nn > 0.02)
+                pb.observe([epi.Transition(prev[e][c], int(np.clip(acts[e][c], 0, 7)), float(rewards[e][c]), s2, done)], [c])
+        prev = states
+    np.testing.assert_array_equal(pa.replay_size(), pb.replay_size())
+    assert (pa.replay_size() == 25).all()                   # 27 pushes into rings of 25: the ring wrapped
+    la, _ = pa.learn([5] * n, None, 2)
+    lb, _ = pb.learn([5] * n, None, 2)
+    np.testing.assert_array_equal(la, lb)
+    assert (la != 0).all()
+    for k in range(n):
+        for x, y in zip(pa.weights(k), pb.weights(k)):
+            np.testing.assert_array_equal(x, y)
+    with pytest.raises(epi.EpiError):                       # a world that keeps nothing has nothing to file
+        w2 = epi.WorldToy(hp, base, batch=1, learning=False)
+        pa.observe_world(w2)
+    w.close(); pa.close(); pb.close()
