@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libepi.so")
+LIB_PATH = os.environ.get("EPI_LIB") or os.path.join(_HERE, "libepi.so")   # EPI_LIB: another build of the same library
 
 EPI_OK, EPI_ERR_BAD_ARGUMENT, EPI_ERR_DEVICE, EPI_ERR_LOCAL_MASS, EPI_ERR_WORLD_MASS, EPI_ERR_ASSERT_STATE, \
     EPI_ERR_INT_RANGE, EPI_ERR_UNSUPPORTED = range(8)

@@ -128,6 +128,25 @@ __device__ __forceinline__ uint32_t wave_min(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t dpp_zero(uint32_t v) {   // lanes without a valid source (or masked out) read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+// Inclusive prefix sum over the 64 lanes (lane l gets v_0 + ... + v_l): three shifted adds of the input inside each
+// group of four lanes, two shifted adds of the partial sums inside each row of 16, two row broadcasts.
+__device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t v) {
+    uint32_t t = v;
+    t += dpp_zero<0x111, 0xf, 0xf>(v);   // row_shr:1
+    t += dpp_zero<0x112, 0xf, 0xf>(v);   // row_shr:2
+    t += dpp_zero<0x113, 0xf, 0xf>(v);   // row_shr:3
+    t += dpp_zero<0x114, 0xf, 0xe>(t);   // row_shr:4 into banks 1..3
+    t += dpp_zero<0x118, 0xf, 0xc>(t);   // row_shr:8 into banks 2..3
+    t += dpp_zero<0x142, 0xa, 0xf>(t);   // row_bcast15 -> rows 1, 3
+    t += dpp_zero<0x143, 0xc, 0xf>(t);   // row_bcast31 -> rows 2, 3
+    return t;
+}
+
 // Sum of non-negative 64-bit values below 2^44 across the wave (world mass check,
 // WorldToy.scala:103-104,142-145): split at bit 22 so both halves fit a 32-bit wave sum.
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
@@ -348,73 +367,21 @@ __device__ __noinline__ uint32_t tie_select(const double* __restrict__ qrow, dou
 // with the remembered density, then interpolation inside the bracket (in the value, and on a cold
 // start alternately in the logarithm, since the high word is exponent-major), with a plain
 // bisection every fourth probe as the safeguard that bounds the iteration count.
+// The search proper, from any valid bracket: #{key >= lo} = clo > rem > chi = #{key >= hi} (clo = n for lo = 0),
+// or `found` with the threshold in `mid`.  Adds the selected units to acc.
 template <int R>
-__device__ __forceinline__ void apportion_row(int32_t E, int n, int diag, const double* __restrict__ qrow,
-                                              uint32_t (&acc)[R], int lane, Warm* warm,
-                                              const double* __restrict__ qtop = nullptr,
-                                              unsigned long long* stats = nullptr) {
-    const double Ed = (double)E;
-    uint32_t key[R];
-    uint32_t bsum = 0;
-    {
-        double q[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) q[r] = qrow[r * 64 + lane];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const double raw = q[r] * Ed;
-            const uint32_t b = (uint32_t)(int32_t)raw;  // raw >= 0: truncation is floor
-            key[r] = (uint32_t)__double2hiint(frac_of(raw));
-            acc[r] += b;
-            bsum += b;
-        }
-    }
-    const uint32_t base_total = wave_sum(bsum);
-    const int32_t rem = (int32_t)((uint32_t)E - base_total);
-    if (stats && lane == 0) atomicAdd(&stats[0], 1ull);
-    if (rem <= 0) return;
-    if (rem >= n) {  // every real column gets a unit (the reference stops at frac.length)
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int j = r * 64 + lane;
-            acc[r] += (j < n && j != diag);
-        }
-        return;
-    }
-    // Wave-uniform search state lives in scalar registers: every value that steers the loop is
-    // passed through readfirstlane so that the branches below are scalar branches.
-    float slope = 0.f;  // value units per element near the threshold (reciprocal density); <= 0: none
-    uint32_t pk = 0u;
-    int32_t prem = 0;
-    if (warm) {
-        slope = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(warm->rho)));
-        pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)warm->key);
-        prem = __builtin_amdgcn_readfirstlane(warm->rem);
-    }
-    const bool cold = !(slope > 0.f);
-    uint32_t lo = 0u, hi = 0x3ff00000u;  // every fraction is below 1.0
-    if (cold) {
-        uint32_t kmax = 0u;
-#pragma unroll
-        for (int r = 0; r < R; ++r) kmax = max(kmax, key[r]);
-        hi = wave_max(kmax) + 1u;
-    }
-    int clo = n, chi = 0, it = 0, last_c = -1;
+__device__ __forceinline__ void search_tail(const uint32_t (&key)[R], uint32_t (&acc)[R], double Ed, int32_t rem, int n,
+                                            int diag, const double* __restrict__ qrow, int lane, Warm* warm, uint32_t hint,
+                                            bool cold, float slope, uint32_t pk, int32_t prem, uint32_t lo, uint32_t hi,
+                                            int clo, int chi, bool lo_probed, bool hi_probed, bool found, uint32_t mid,
+                                            unsigned long long* stats) {
+    int it = 0, last_c = -1;
     uint32_t last_k = 0u;
-    bool lo_probed = false, hi_probed = false;
-    // No column received a whole unit: every fraction is the product q_j * E itself, so the rem = E
-    // largest are the E largest weights of the row.  qtop holds the row's kTopWeights largest
-    // weights in descending order; the E-th of them times E is the threshold to try first.
-    uint32_t hint = 0u;
-    if (qtop && base_total == 0u && E < kTopWeights)
-        hint = (uint32_t)__builtin_amdgcn_readfirstlane(__double2hiint(qtop[E - 1] * Ed));
-    bool found = false;
-    uint32_t mid = 0u;
     // A bracket end that was probed and is within kSnap elements of the target is moved element by
     // element instead: the smallest key >= lo (or the largest key < hi) is an exact next threshold, found
     // with one min (max) reduction, and the probe that follows it always makes progress.
     constexpr int kSnap = (R <= 4) ? 2 : 1;  // measured best on the 200- and the 1,000-country grids
-    while (hi - lo > 1u) {
+    while (!found && hi - lo > 1u) {
         if (lo_probed && clo - rem <= kSnap && !(hi_probed && rem - chi < clo - rem)) {
             uint32_t x = 0xffffffffu;
 #pragma unroll
@@ -473,7 +440,7 @@ __device__ __forceinline__ void apportion_row(int32_t E, int n, int diag, const 
     if (stats && lane == 0) {
         atomicAdd(&stats[1], (unsigned long long)it);
         atomicAdd(&stats[2], cold ? 1ull : 0ull);
-        if (found) atomicAdd(&stats[4 + min(it - 1, 27)], 1ull);
+        if (found) atomicAdd(&stats[4 + min(it, 27)], 1ull);   // histogram index = counting probes used
         else atomicAdd(&stats[3], 1ull);
     }
     if (found) {
@@ -496,6 +463,184 @@ __device__ __forceinline__ void apportion_row(int32_t E, int n, int diag, const 
         warm->rho = slope;
         warm->rem = rem;
     }
+}
+
+template <int R>
+__device__ __forceinline__ void apportion_row(int32_t E, int n, int diag, const double* __restrict__ qrow,
+                                              uint32_t (&acc)[R], int lane, Warm* warm,
+                                              const double* __restrict__ qtop = nullptr,
+                                              unsigned long long* stats_in = nullptr) {
+#ifdef EPI_SEARCH_STATS
+    unsigned long long* stats = stats_in;   // search statistics are compiled in on request only: they cost registers
+#else
+    (void)stats_in;
+    constexpr unsigned long long* stats = nullptr;
+#endif
+    const double Ed = (double)E;
+    uint32_t key[R];
+    uint32_t bsum = 0;
+    {
+        double q[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) q[r] = qrow[r * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double raw = q[r] * Ed;
+            const uint32_t b = (uint32_t)(int32_t)raw;  // raw >= 0: truncation is floor
+            key[r] = (uint32_t)__double2hiint(frac_of(raw));
+            acc[r] += b;
+            bsum += b;
+        }
+    }
+    const uint32_t base_total = wave_sum(bsum);
+    const int32_t rem = (int32_t)((uint32_t)E - base_total);
+    if (stats && lane == 0) atomicAdd(&stats[0], 1ull);
+    if (rem <= 0) return;
+    if (rem >= n) {  // every real column gets a unit (the reference stops at frac.length)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j = r * 64 + lane;
+            acc[r] += (j < n && j != diag);
+        }
+        return;
+    }
+    // Wave-uniform search state lives in scalar registers: every value that steers the loop is
+    // passed through readfirstlane so that the branches below are scalar branches.
+    float slope = 0.f;  // value units per element near the threshold (reciprocal density); <= 0: none
+    uint32_t pk = 0u;
+    int32_t prem = 0;
+    if (warm) {
+        slope = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(warm->rho)));
+        pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)warm->key);
+        prem = __builtin_amdgcn_readfirstlane(warm->rem);
+    }
+    const bool cold = !(slope > 0.f);
+    uint32_t hi = 0x3ff00000u;  // every fraction is below 1.0
+    if (cold) {
+        uint32_t kmax = 0u;
+#pragma unroll
+        for (int r = 0; r < R; ++r) kmax = max(kmax, key[r]);
+        hi = wave_max(kmax) + 1u;
+    }
+    // No column received a whole unit: every fraction is the product q_j * E itself, so the rem = E
+    // largest are the E largest weights of the row.  qtop holds the row's kTopWeights largest
+    // weights in descending order; the E-th of them times E is the threshold to try first.
+    uint32_t hint = 0u;
+    if (qtop && base_total == 0u && E < kTopWeights)
+        hint = (uint32_t)__builtin_amdgcn_readfirstlane(__double2hiint(qtop[E - 1] * Ed));
+    search_tail<R>(key, acc, Ed, rem, n, diag, qrow, lane, warm, hint, cold, slope, pk, prem, 0u, hi, n, 0, false, false, false, 0u,
+                   stats);
+}
+
+// apportion_row started from a histogram of the fractions.  `hist`: 64 * R zeroed LDS words owned by the calling wave
+// (zero again on return).
+//
+// A fraction's bucket is floor(value * NB) of the double whose high word its key is, NB = 64 * R: monotone in the key,
+// bucket edges at the keys of b / NB (whose low words are zero).  Lane l reads back buckets R*l .. R*l + R - 1, so a
+// prefix sum over the lanes counts the smaller fractions; the bucket that holds the rem-th largest one and the counts
+// on either side of it come out of one scatter, one prefix scan and one ballot -- no data-dependent loop and hardly
+// any scalar bookkeeping.  When the bucket's lower edge already separates exactly rem fractions (about two times in
+// three when there is one bucket per column) that edge is the threshold; otherwise the search continues inside the
+// bucket, which holds a handful of fractions.  Measured on the 200-country grid against the warm-started search:
+// 263 -> 201 vector and 290 -> 95 scalar instructions per row.  (Running the S and the I split of a row side by side
+// through this code was tried: more instructions -- 214 / 150 -- and no gain.)
+template <int R>
+__device__ __forceinline__ void apportion_row_hist(int32_t E, int n, int diag, const double* __restrict__ qrow,
+                                                   uint32_t (&acc)[R], int lane, uint32_t* hist,
+                                                   unsigned long long* stats_in = nullptr) {
+#ifdef EPI_SEARCH_STATS
+    unsigned long long* stats = stats_in;
+#else
+    (void)stats_in;
+    constexpr unsigned long long* stats = nullptr;
+#endif
+    constexpr int NB = 64 * R;
+    const double Ed = (double)E;
+    uint32_t key[R];
+    uint32_t bsum = 0;
+    {
+        double q[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) q[r] = qrow[r * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double raw = q[r] * Ed;
+            const uint32_t b = (uint32_t)(int32_t)raw;  // raw >= 0: truncation is floor
+            key[r] = (uint32_t)__double2hiint(frac_of(raw));
+            acc[r] += b;
+            bsum += b;
+        }
+    }
+    const uint32_t base_total = wave_sum(bsum);
+    const int32_t rem = (int32_t)((uint32_t)E - base_total);
+    if (stats && lane == 0) atomicAdd(&stats[0], 1ull);
+    if (rem <= 0) return;
+    if (rem >= n) {  // every real column gets a unit (the reference stops at frac.length)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j = r * 64 + lane;
+            acc[r] += (j < n && j != diag);
+        }
+        return;
+    }
+    // padding columns (weight 0, fraction 0) stay out: dozens of lanes adding to one word would queue up behind each other
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (r * 64 + lane < n) atomicAdd(&hist[(uint32_t)(from_hi_word(key[r]) * (double)NB)], 1u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint32_t c[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) c[k] = hist[R * lane + k];
+#pragma unroll
+    for (int k = 0; k < R; ++k) hist[R * lane + k] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int k = 1; k < R; ++k) c[k] += c[k - 1];
+    const uint32_t P = wave_prefix_sum(c[R - 1]);     // fractions in this lane's buckets and all lower ones
+    const uint32_t e = P - c[R - 1];                  // ... in all lower lanes' buckets
+    // #{bucket >= B} >= rem  <=>  #{bucket < B} <= n - rem: the highest bucket B with that property holds the rem-th largest
+    const uint32_t T = (uint32_t)(n - rem);
+    const unsigned long long reach = __ballot(e <= T);   // never empty: lane 0 has e = 0
+    const int L = __builtin_amdgcn_readfirstlane(63 - (int)__builtin_clzll(reach | 1ull));
+    int kidx, below;   // bucket R*L + kidx; fractions in lower buckets; `inside` = fractions in the bucket itself
+    int inside;
+    if constexpr (R <= 4) {
+        uint32_t kk = 0u, vbelow = e, vnext = P;
+#pragma unroll
+        for (int k = 0; k < R - 1; ++k) {
+            const uint32_t ck = e + c[k];            // #{bucket <= R*lane + k}
+            const bool ok = ck <= T;                 // bucket R*lane + k + 1 still qualifies
+            kk += ok;
+            vbelow = ok ? ck : vbelow;
+        }
+#pragma unroll
+        for (int k = R - 2; k >= 0; --k) {
+            const uint32_t ck = e + c[k];
+            vnext = (ck > T) ? ck : vnext;           // smallest cumulative count above T: #{bucket <= B}
+        }
+        kidx = __builtin_amdgcn_readlane((int)kk, L);
+        below = __builtin_amdgcn_readlane((int)vbelow, L);
+        inside = __builtin_amdgcn_readlane((int)vnext, L) - below;
+    } else {
+        // wide rows: the walk over the lane's R buckets runs on the scalar unit
+        const int base = __builtin_amdgcn_readlane((int)e, L);
+        kidx = 0;
+        below = base;
+        int next = base + __builtin_amdgcn_readlane((int)c[R - 1], L);
+#pragma unroll
+        for (int k = R - 2; k >= 0; --k) {
+            const int ck = base + __builtin_amdgcn_readlane((int)c[k], L);
+            if (ck > (int)T) next = ck;
+            if (ck <= (int)T && kidx == 0) { kidx = k + 1; below = ck; }
+        }
+        inside = next - below;
+    }
+    const int bucket = R * L + kidx;
+    const int chi = n - below - inside, clo = n - below;   // #{key >= upper edge}, #{key >= lower edge}
+    const uint32_t lo = bucket == 0 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane(__double2hiint((double)bucket * (1.0 / NB)));
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane(__double2hiint((double)(bucket + 1) * (1.0 / NB)));
+    search_tail<R>(key, acc, Ed, rem, n, diag, qrow, lane, nullptr, 0u, false, 0.f, 0u, 0, lo, hi, clo, chi, true, true,
+                   clo == rem && bucket != 0, lo, stats);
 }
 
 }  // namespace dev

@@ -48,8 +48,17 @@ __device__ __forceinline__ void record_error(int* sh_err, int code, int node, in
 // 64 * R own one country each in the local and apply phases; every wave takes rows in the mobility phase, so
 // small worlds, whose episodes would otherwise run on one to four waves, get W >= R waves to hide the latency of
 // the search's dependent steps.
+#ifndef EPI_SMALL_WPE
+#define EPI_SMALL_WPE 8
+#endif
+#ifndef EPI_KW4
+#define EPI_KW4 16
+#endif
+#ifndef EPI_HIST_MAXR
+#define EPI_HIST_MAXR 8
+#endif
 template <int R, int W>
-__global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(W > R ? 8 : 1)))  /* small worlds: 64 registers, twice the resident waves */ void episode_dense_kernel(const EpisodeArgs a) {
+__global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(W > R ? EPI_SMALL_WPE : 1)))  /* small worlds: 64 registers, twice the resident waves */ void episode_dense_kernel(const EpisodeArgs a) {
     constexpr int NP = R * 64;
     static_assert(W >= R, "every padded country needs a thread");
     __shared__ int32_t sh_s[NP], sh_i[NP], sh_r[NP], sh_d[NP], sh_v[NP];
@@ -59,7 +68,14 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(W > R ? 
     __shared__ unsigned long long sh_mass[2][2];
     __shared__ int sh_next_row;
     __shared__ int sh_err[4];
-    __shared__ Warm sh_warm[2][NP];  // threshold-search memory per (compartment, row)
+    // threshold search: rows of up to 512 columns start from a histogram of their fractions (apportion_row_hist; one
+    // zeroed block of 64 * R words per wave); wider rows remember the previous day's threshold per (compartment, row)
+    // and search from there.  Measured, country-steps/s with / without the histogram: 200 countries 2.79e9 / 1.66e9,
+    // 400: 1.71e9 / 1.47e9, 500: 1.60e9 / 1.49e9, 1,000: 7.0e8 / 8.6e8 (16 LDS atomics and a scalar walk over 16
+    // buckets per split cost more than the probes they save).
+    constexpr bool kHist = R <= EPI_HIST_MAXR;
+    __shared__ Warm sh_warm[kHist ? 1 : 2][kHist ? 1 : NP];
+    __shared__ uint32_t sh_hist[kHist ? W : 1][kHist ? NP : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -85,9 +101,13 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(W > R ? 
         tcur = a.tcur[eoff + tid];
         arrival = a.arrival[eoff + tid];
         peak = a.peak[eoff + tid];
-        sh_warm[0][tid].rho = 0.f;
-        sh_warm[1][tid].rho = 0.f;
+        if constexpr (!kHist) {
+            sh_warm[0][tid].rho = 0.f;
+            sh_warm[1][tid].rho = 0.f;
+        }
     }
+    if constexpr (kHist)
+        for (int k = tid; k < W * NP; k += W * 64) (&sh_hist[0][0])[k] = 0u;
     int32_t last_flow_s = 0, last_flow_i = 0;
     if (tid == 0) {
         sh_mass[0][0] = sh_mass[0][1] = sh_mass[1][0] = sh_mass[1][1] = 0ull;
@@ -96,7 +116,16 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(W > R ? 
     const double my_sumw = real ? ((tid == a.seed_idx && a.qseed) ? a.sumw_seed[ti] : a.sumw[tid]) : 0.0;
     __syncthreads();
 
+#ifdef EPI_DENSE_TIMERS
+    long long tmr[6] = {0, 0, 0, 0, 0, 0};   // per wave: phase A, barrier, phase B rows, B merge + barrier, phase C, rows taken
+#define EPI_DT(i) { const long long k1_ = clock64(); tmr[i] += k1_ - k0_; k0_ = k1_; }
+#else
+#define EPI_DT(i)
+#endif
     for (int t = a.t_begin; t < a.t_end; ++t) {
+#ifdef EPI_DENSE_TIMERS
+        long long k0_ = clock64();
+#endif
         // ------------------------------------------------------------------ phase A
         if (tid == 0) sh_next_row = 0;
         if (own) {
@@ -152,7 +181,9 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(W > R ? 
             const unsigned long long wsum = wave_sum_u64(mass_local);
             if (lane == 0) atomicAdd(&sh_mass[t & 1][0], wsum);
         }
+        EPI_DT(0)
         __syncthreads();
+        EPI_DT(1)
 
         // ------------------------------------------------------------------ phase B
         if (tid == 0 && a.validate && t > a.t_begin) {
@@ -176,15 +207,25 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(W > R ? 
                 if ((ES | EI) == 0) continue;
                 const double* __restrict__ qrow =
                     (row == a.seed_idx && a.qseed) ? a.qseed + (size_t)ti * NP : a.q + (size_t)row * NP;
-                const double* __restrict__ qtop =
-                    !a.qtop ? nullptr
-                            : ((row == a.seed_idx && a.qseed) ? a.qtop_seed + (size_t)ti * kTopWeights
-                                                              : a.qtop + (size_t)row * kTopWeights);
-                if (ES > 0) apportion_row<R>(ES, n, row, qrow, accS, lane, &sh_warm[0][row], qtop, a.stats);
-                if (EI > 0)
-                    apportion_row<R>(EI, n, row, qrow, accI, lane, &sh_warm[1][row], qtop, a.stats ? a.stats + 32 : nullptr);
+                if constexpr (kHist) {
+                    uint32_t* hist = &sh_hist[tid >> 6][0];
+                    if (ES > 0) apportion_row_hist<R>(ES, n, row, qrow, accS, lane, hist, a.stats);
+                    if (EI > 0) apportion_row_hist<R>(EI, n, row, qrow, accI, lane, hist, a.stats ? a.stats + 32 : nullptr);
+                } else {
+                    const double* __restrict__ qtop =
+                        !a.qtop ? nullptr
+                                : ((row == a.seed_idx && a.qseed) ? a.qtop_seed + (size_t)ti * kTopWeights
+                                                                  : a.qtop + (size_t)row * kTopWeights);
+                    if (ES > 0) apportion_row<R>(ES, n, row, qrow, accS, lane, &sh_warm[0][row], qtop, a.stats);
+                    if (EI > 0)
+                        apportion_row<R>(EI, n, row, qrow, accI, lane, &sh_warm[1][row], qtop, a.stats ? a.stats + 32 : nullptr);
+                }
                 any = true;
+#ifdef EPI_DENSE_TIMERS
+                tmr[5] += 1;
+#endif
             }
+            EPI_DT(2)
             if (any) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -194,6 +235,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(W > R ? 
             }
         }
         __syncthreads();
+        EPI_DT(3)
 
         // ------------------------------------------------------------------ phase C
         unsigned long long mass_move = 0ull;
@@ -221,7 +263,12 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(W > R ? 
         }
         // No barrier here: phase A of the next step touches only this thread's own slots, and every
         // wave has left the row loop before the barrier above.
+        EPI_DT(4)
     }
+#ifdef EPI_DENSE_TIMERS
+    if (a.stats && lane == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(&a.stats[48 + i], (unsigned long long)tmr[i]);
+#endif
     __syncthreads();
     if (tid == 0) {
         if (a.validate && a.t_end > a.t_begin) {
@@ -1054,7 +1101,7 @@ hipError_t launch_episode(const EpisodeArgs& a, hipStream_t s) {
     // 1.22e9, 8 waves 1.27e9, 8 waves within 64 registers 1.53e9, 16 waves within 64 registers 1.66e9 country-steps/s;
     // 400 to 500 countries: 8 waves 1.10e9, 8 waves within 64 registers 1.33e9, 16 waves within 64 registers 1.46e9).
     // The 16-slot variant cannot follow: within 64 registers it spills its keys and runs seven times slower.
-    constexpr int kW1 = 4, kW2 = 8, kW4 = 16;
+    constexpr int kW1 = 4, kW2 = 8, kW4 = EPI_KW4;
     switch (a.npad / 64) {
         case 1: hipLaunchKernelGGL((episode_dense_kernel<1, kW1>), grid, dim3(64 * kW1), 0, s, a); break;
         case 2: hipLaunchKernelGGL((episode_dense_kernel<2, kW2>), grid, dim3(64 * kW2), 0, s, a); break;
