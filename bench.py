@@ -214,8 +214,9 @@ def run_c5(args, rank, local_rank, world, use_dist):
                      "launches": int(k_launches), "avg_launch_ms": k_ms / max(1, k_launches),
                      "algorithmic_bytes_per_country_step": bpcs,
                      "algorithmic_bytes_per_launch": B * n * bpcs,
-                     "note": "one-step launches of 4,096 six-country worlds: launch- and transfer-bound, "
-                             "the kernel itself takes avg_launch_ms of ms_per_step"},
+                     "note": "one launch per step of 4,096 six-country worlds; the kernel reads the actions from and writes "
+                             "states and rewards to page-locked host memory itself, so avg_launch_ms is mostly the PCIe "
+                             "transfer (1.9 MB per step) and the HBM roofline does not describe it"},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -1032,6 +1032,12 @@ static int32_t grid_enqueue(epi_grid* g, int32_t g_begin, int32_t g_stride, int3
                             int32_t* d_arr, double* d_pk, hipStream_t s, bool may_allocate) {
     const int n = g->n, npad = g->npad;
     int32_t rc;
+    // one outstanding run per handle: the work buffers and the error table are shared, so an earlier run that was
+    // only enqueued is waited for and its status collected before they are overwritten (its failure is returned here)
+    if (g->pending) {
+        rc = epi_grid_status(g);
+        if (rc) return rc;
+    }
     InitArgs ia{};
     ia.n = n; ia.npad = npad; ia.count = g_count; ia.seed_idx = g->seed_idx;
     ia.pop = g->graph.pop.as<int32_t>();

@@ -188,7 +188,8 @@ int32_t epi_grid_run_strided(epi_grid *g, int32_t g_begin, int32_t g_stride, int
  * stream are ordered and safe); it is overwritten from the start by every call. */
 int32_t epi_grid_run_noalloc(epi_grid *g, int32_t g_begin, int32_t g_stride, int32_t g_count, double *loss_dev,
                              int32_t *arrival_dev, double *peak_dev, void *stream);
-/* Waits for the last enqueued run and returns its status (first failing grid point wins). */
+/* Waits for the last enqueued run and returns its status (first failing grid point wins).  A handle holds one
+ * outstanding run: enqueueing another one first waits for the earlier one and returns its failure, if any. */
 int32_t epi_grid_status(epi_grid *g);
 int32_t epi_grid_destroy(epi_grid *g);
 /* Measurement hooks (no counterpart in the reference).  With timing on, every launch of the episode
@@ -279,7 +280,11 @@ int32_t epi_world_keep_transitions(epi_world *w, int32_t on);
 int32_t epi_world_set_mlp(epi_world *w, int32_t hidden, const double *W1, const double *b1, const double *W2,
                           const double *b2, const double *W3, const double *b3, double clip_q);
 int32_t epi_world_get_states(epi_world *w, epi_state *out);       /* snapshotStates :75 */
-int32_t epi_world_set_states(epi_world *w, const epi_state *in);  /* restoreStates  :76 */
+/* restoreStates :76.  Deliberate restrictions: compartments must be non-negative integers below 2^31 (what every
+ * state the engine or the reference's own step produces holds; the reference would round other values at its next
+ * env.step, env.scala:81-85), and the states' t_max / seed fields are not kept -- every instance uses the base
+ * state's t_max, as every state a WorldToy produces does. */
+int32_t epi_world_set_states(epi_world *w, const epi_state *in);
 int32_t epi_world_reset(epi_world *w);                            /* resetToInitial :77 */
 /* Net S and I flows of the last step, movedS/movedI[batch][n] (WorldToy.scala:106-126). */
 int32_t epi_world_last_flows(epi_world *w, int32_t *moved_s, int32_t *moved_i);
