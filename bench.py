@@ -433,6 +433,11 @@ def main():
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
         world = dist.get_world_size()
+        # RCCL builds its rings on the first collective: do that here, outside every timed region, whatever --warmup says
+        warm = torch.zeros(max(1, world), dtype=torch.float64, device="cuda")
+        dist.all_reduce(warm)
+        dist.all_gather_into_tensor(torch.empty(world * world, dtype=torch.float64, device="cuda"), warm)
+        torch.cuda.synchronize()
     if args.cpu_threads <= 0:
         args.cpu_threads = host_cores()
 

@@ -116,6 +116,9 @@ def lib():
         L.epi_grid_run_noalloc.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p]
         L.epi_grid_status.argtypes = [C.c_void_p]
+        L.epi_calibrate_grid.argtypes = [C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, _PI, _PD]
+        L.epi_grid_create.argtypes = [C.POINTER(GridDesc)]
+        L.epi_world_create.argtypes = [C.POINTER(WorldDesc)]
         L.epi_grid_multi_create.restype = C.c_void_p
         L.epi_grid_multi_create.argtypes = [C.POINTER(GridDesc), _PI, C.c_int32]
         L.epi_grid_multi_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _PI, _PD]
