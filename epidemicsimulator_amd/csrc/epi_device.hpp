@@ -465,34 +465,12 @@ __device__ __forceinline__ void search_tail(const uint32_t (&key)[R], uint32_t (
     }
 }
 
+// The warm-started search of one compartment from keys that are already formed (base_total = whole units handed out).
 template <int R>
-__device__ __forceinline__ void apportion_row(int32_t E, int n, int diag, const double* __restrict__ qrow,
-                                              uint32_t (&acc)[R], int lane, Warm* warm,
-                                              const double* __restrict__ qtop = nullptr,
-                                              unsigned long long* stats_in = nullptr) {
-#ifdef EPI_SEARCH_STATS
-    unsigned long long* stats = stats_in;   // search statistics are compiled in on request only: they cost registers
-#else
-    (void)stats_in;
-    constexpr unsigned long long* stats = nullptr;
-#endif
+__device__ __forceinline__ void search_from_keys(const uint32_t (&key)[R], uint32_t (&acc)[R], int32_t E, uint32_t base_total, int n,
+                                                 int diag, const double* __restrict__ qrow, int lane, Warm* warm,
+                                                 const double* __restrict__ qtop, unsigned long long* stats) {
     const double Ed = (double)E;
-    uint32_t key[R];
-    uint32_t bsum = 0;
-    {
-        double q[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) q[r] = qrow[r * 64 + lane];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const double raw = q[r] * Ed;
-            const uint32_t b = (uint32_t)(int32_t)raw;  // raw >= 0: truncation is floor
-            key[r] = (uint32_t)__double2hiint(frac_of(raw));
-            acc[r] += b;
-            bsum += b;
-        }
-    }
-    const uint32_t base_total = wave_sum(bsum);
     const int32_t rem = (int32_t)((uint32_t)E - base_total);
     if (stats && lane == 0) atomicAdd(&stats[0], 1ull);
     if (rem <= 0) return;
@@ -530,6 +508,36 @@ __device__ __forceinline__ void apportion_row(int32_t E, int n, int diag, const 
         hint = (uint32_t)__builtin_amdgcn_readfirstlane(__double2hiint(qtop[E - 1] * Ed));
     search_tail<R>(key, acc, Ed, rem, n, diag, qrow, lane, warm, hint, cold, slope, pk, prem, 0u, hi, n, 0, false, false, false, 0u,
                    stats);
+}
+
+template <int R>
+__device__ __forceinline__ void apportion_row(int32_t E, int n, int diag, const double* __restrict__ qrow,
+                                              uint32_t (&acc)[R], int lane, Warm* warm,
+                                              const double* __restrict__ qtop = nullptr,
+                                              unsigned long long* stats_in = nullptr) {
+#ifdef EPI_SEARCH_STATS
+    unsigned long long* stats = stats_in;   // search statistics are compiled in on request only: they cost registers
+#else
+    (void)stats_in;
+    constexpr unsigned long long* stats = nullptr;
+#endif
+    const double Ed = (double)E;
+    uint32_t key[R];
+    uint32_t bsum = 0;
+    {
+        double q[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) q[r] = qrow[r * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double raw = q[r] * Ed;
+            const uint32_t b = (uint32_t)(int32_t)raw;  // raw >= 0: truncation is floor
+            key[r] = (uint32_t)__double2hiint(frac_of(raw));
+            acc[r] += b;
+            bsum += b;
+        }
+    }
+    search_from_keys<R>(key, acc, E, wave_sum(bsum), n, diag, qrow, lane, warm, qtop, stats);
 }
 
 // apportion_row started from a histogram of the fractions.  `hist`: 64 * R zeroed LDS words owned by the calling wave
