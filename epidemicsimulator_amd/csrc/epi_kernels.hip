@@ -339,11 +339,13 @@ __device__ __forceinline__ const T* group_ptr(const T* p, int k0) {
 // from the weights, which is what the rare tie path and the scatter pass do instead of keeping them.
 struct LaneThreshold {
     uint32_t Kx, picked;
+    bool bad;  // more units left over than positive fractions: the graph sends units to entries that are not stored
 };
 
 // STRIDE: distance in elements between consecutive weights of the lane's row (64 in the slot-major
 // layout of sparse graphs, 1 for a plain row).
-template <int DMAX, int STRIDE = 64>
+// STORED_ONLY: the row is a sparse one, whose units must all land on stored entries (`bad` otherwise).
+template <int DMAX, int STRIDE = 64, bool STORED_ONLY = true>
 __device__ __forceinline__ LaneThreshold lane_threshold(uint32_t (&srt)[DMAX], int32_t rem, double Ed, int D,
                                                         const double* __restrict__ qp) {
     // K = the rem-th largest key, read from the sorted keys (sorting network: no data-dependent control
@@ -356,12 +358,29 @@ __device__ __forceinline__ LaneThreshold lane_threshold(uint32_t (&srt)[DMAX], i
         K = hit ? srt[j] : K;
         if (j + 1 < DMAX) nxt = hit ? srt[j + 1] : nxt;
     }
+    // A unit may land on stored entries only: rem must not exceed the number of positive fractions, or else the
+    // rem-th largest fraction is 0.  Its key is then 0 as well; a key of 0 with a positive fraction (below 2^-1022)
+    // takes an absurd graph, so the positive fractions are counted exactly in that case only.
+    LaneThreshold r;
+    r.picked = 0u;
+    r.bad = false;
+    if (STORED_ONLY && __any(rem > 0 && K == 0u)) {
+        int pos = 0;
+#pragma unroll
+        for (int k0 = 0; k0 < DMAX; k0 += kSlotGroup) {
+            if (k0 < D) {
+                const double* qg = group_ptr<double, STRIDE>(qp, k0);
+#pragma unroll
+                for (int j = 0; j < kSlotGroup; ++j) pos += (frac_of(qg[j * STRIDE] * Ed) > 0.0);  // slots past D hold weight 0
+            }
+        }
+        r.bad = rem > pos;
+        if (r.bad) rem = 0;
+    }
     // ranks rem and rem+1 differ in the high word: every key >= K is selected.  Otherwise m = rem - #{key > K}
     // members of the tie are picked one at a time; they are few unless weights repeat
     const bool found = rem > 0 && (rem == DMAX || nxt != K);
     const bool tie = rem > 0 && !found;
-    LaneThreshold r;
-    r.picked = 0u;
     if (__any(tie)) {
         int above = 0;
 #pragma unroll
@@ -404,7 +423,7 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
     constexpr int HALF = (DMAX % (2 * kSlotGroup) == 0) ? DMAX / 2 : kSlotGroup;
     const double EdS = (double)ES, EdI = (double)EI;
     uint32_t keyS[DMAX], keyI[DMAX];
-    uint32_t bsumS = 0u, bsumI = 0u, posS = 0u, posI = 0u;
+    uint32_t bsumS = 0u, bsumI = 0u;
     EPI_TM(long long c0 = clock64();)
 #pragma unroll
     for (int h0 = 0; h0 < DMAX; h0 += HALF) {
@@ -423,64 +442,66 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
         for (int j = 0; j < HALF; ++j) {
             const int k = h0 + j;
             const double rawS = qv[j] * EdS;  // slots past D of a group that is read hold weight 0
-            const double frS = frac_of(rawS);
             bsumS += (uint32_t)(int32_t)rawS;
-            keyS[k] = (uint32_t)__double2hiint(frS);
-            posS += (frS > 0.0);
+            keyS[k] = (uint32_t)__double2hiint(frac_of(rawS));
             const double rawI = qv[j] * EdI;
-            const double frI = frac_of(rawI);
             bsumI += (uint32_t)(int32_t)rawI;
-            keyI[k] = (uint32_t)__double2hiint(frI);
-            posI += (frI > 0.0);
+            keyI[k] = (uint32_t)__double2hiint(frac_of(rawI));
         }
     }
-    int32_t remS = (int32_t)((uint32_t)ES - bsumS), remI = (int32_t)((uint32_t)EI - bsumI);
-    if (remS > (int32_t)posS || remI > (int32_t)posI) {
-        record_error(sh_err, EPI_ERR_UNSUPPORTED, row, t);
-        remS = remI = 0;
-    }
+    const int32_t remS = (int32_t)((uint32_t)ES - bsumS), remI = (int32_t)((uint32_t)EI - bsumI);
     EPI_TM(asm volatile("" ::"v"(remS), "v"(remI)); { const long long c1 = clock64(); tm[0] += c1 - c0; c0 = c1; })
     const LaneThreshold thS = lane_threshold<DMAX>(keyS, remS, EdS, D, qp);
     LaneThreshold thI;
     thI.Kx = 0xffffffffu;
     thI.picked = 0u;
+    thI.bad = false;
     if (anyI) thI = lane_threshold<DMAX>(keyI, remI, EdI, D, qp);
+    if (thS.bad || thI.bad) record_error(sh_err, EPI_ERR_UNSUPPORTED, row, t);
     EPI_TM(asm volatile("" ::"v"(thS.Kx), "v"(thI.Kx)); { const long long c1 = clock64(); tm[1] += c1 - c0; c0 = c1; })
     // A unit lands only on stored off-diagonal entries: padding and a stored diagonal hold weight 0, hence
     // base 0 and fraction 0, and fractions that are 0 are never selected (rem <= #positive fractions).
+    // Ties in a high word are rare: the pass that also looks at the picked bits runs only when a lane has some.
+    auto scatter = [&](auto with_picked) {
+        constexpr bool kPicked = decltype(with_picked)::value;
 #pragma unroll
-    for (int h0 = 0; h0 < DMAX; h0 += HALF) {
-        if (h0 < D) {
-            double qv[HALF];
-            int cv[HALF];
+        for (int h0 = 0; h0 < DMAX; h0 += HALF) {
+            if (h0 < D) {
+                double qv[HALF];
+                int cv[HALF];
 #pragma unroll
-            for (int k0 = 0; k0 < HALF; k0 += kSlotGroup) {
+                for (int k0 = 0; k0 < HALF; k0 += kSlotGroup) {
 #pragma unroll
-                for (int j = 0; j < kSlotGroup; ++j) { qv[k0 + j] = 0.0; cv[k0 + j] = 0; }
-                if (h0 + k0 < D) {
-                    const double* qg = group_ptr(qp, h0 + k0);
-                    const int32_t* cg = group_ptr(cp, h0 + k0);
+                    for (int j = 0; j < kSlotGroup; ++j) { qv[k0 + j] = 0.0; cv[k0 + j] = 0; }
+                    if (h0 + k0 < D) {
+                        const double* qg = group_ptr(qp, h0 + k0);
+                        const int32_t* cg = group_ptr(cp, h0 + k0);
 #pragma unroll
-                    for (int j = 0; j < kSlotGroup; ++j) {
-                        qv[k0 + j] = qg[j * 64];
-                        cv[k0 + j] = cg[j * 64];
+                        for (int j = 0; j < kSlotGroup; ++j) {
+                            qv[k0 + j] = qg[j * 64];
+                            cv[k0 + j] = cg[j * 64];
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int j = 0; j < HALF; ++j) {
-                const int k = h0 + j;
-                const double rawS = qv[j] * EdS;
-                const uint32_t selS = (uint32_t)((uint32_t)__double2hiint(frac_of(rawS)) >= thS.Kx) | ((thS.picked >> k) & 1u);
-                const uint32_t allocS = (uint32_t)(int32_t)rawS + selS;
-                if (allocS != 0u) atomicAdd(&sh_movS[cv[j]], allocS);
-                const double rawI = qv[j] * EdI;
-                const uint32_t selI = (uint32_t)((uint32_t)__double2hiint(frac_of(rawI)) >= thI.Kx) | ((thI.picked >> k) & 1u);
-                const uint32_t allocI = (uint32_t)(int32_t)rawI + selI;
-                if (allocI != 0u) atomicAdd(&sh_movI[cv[j]], allocI);
+                for (int j = 0; j < HALF; ++j) {
+                    const int k = h0 + j;
+                    const double rawS = qv[j] * EdS;
+                    uint32_t selS = (uint32_t)((uint32_t)__double2hiint(frac_of(rawS)) >= thS.Kx);
+                    if constexpr (kPicked) selS |= (thS.picked >> k) & 1u;
+                    const uint32_t allocS = (uint32_t)(int32_t)rawS + selS;
+                    if (allocS != 0u) atomicAdd(&sh_movS[cv[j]], allocS);
+                    const double rawI = qv[j] * EdI;
+                    uint32_t selI = (uint32_t)((uint32_t)__double2hiint(frac_of(rawI)) >= thI.Kx);
+                    if constexpr (kPicked) selI |= (thI.picked >> k) & 1u;
+                    const uint32_t allocI = (uint32_t)(int32_t)rawI + selI;
+                    if (allocI != 0u) atomicAdd(&sh_movI[cv[j]], allocI);
+                }
             }
         }
-    }
+    };
+    if (__any((thS.picked | thI.picked) != 0u)) scatter(std::true_type{});
+    else scatter(std::false_type{});
     EPI_TM(__builtin_amdgcn_s_waitcnt(0); { const long long c1 = clock64(); tm[2] += c1 - c0; })
 }
 
@@ -915,7 +936,7 @@ __device__ __forceinline__ void tiny_split(int32_t E, const double (&q)[kTinyN],
         srt[j] = (uint32_t)__double2hiint(frac_of(raw));
     }
     const int32_t rem = E > 0 ? (int32_t)((uint32_t)E - bsum) : 0;
-    const LaneThreshold th = lane_threshold<kTinyN, 1>(srt, rem, Ed, n, qrow);
+    const LaneThreshold th = lane_threshold<kTinyN, 1, false>(srt, rem, Ed, n, qrow);  // a dense row: zero fractions take units too
 #pragma unroll
     for (int j = 0; j < kTinyN; ++j) {
         const double raw = q[j] * Ed;
@@ -1159,26 +1180,51 @@ hipError_t launch_init(const InitArgs& a, hipStream_t s) {
 // Loss of one grid point (Calibrate.scala:14-17,103-109): the two root-mean-squares are summed
 // over countries in order by one lane so that every rounding matches the sequential reference.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void loss_kernel(const LossArgs a) {
+constexpr int kLossThreads = 256;
+constexpr int kLossChunk = 1024;   // countries whose squared errors are staged in LDS at a time
+
+// One workgroup per episode.  The squared errors are formed by all threads, a chunk of countries at a time; the two
+// sums run over them in country order on one thread each (Seq.sum adds left to right), reading LDS instead of
+// waiting for one memory round trip per country.
+__global__ __launch_bounds__(kLossThreads) void loss_kernel(const LossArgs a) {
+    __shared__ double sh_qa[kLossChunk], sh_qp[kLossChunk];
+    __shared__ double sh_sp;
     const int e = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
     const size_t eoff = (size_t)e * a.npad;
-    for (int c = lane; c < a.n; c += 64) {
-        const int32_t arr = a.arrival[eoff + c] < 0 ? a.steps : a.arrival[eoff + c];
-        if (a.arrival_out) a.arrival_out[(size_t)e * a.n + c] = arr;
-        if (a.peak_out) a.peak_out[(size_t)e * a.n + c] = (double)a.peak[eoff + c];
+    double sum = 0.0;   // thread 0: arrival errors, thread 64: peak errors
+    for (int c0 = 0; c0 < a.n; c0 += kLossChunk) {
+        const int m = min(kLossChunk, a.n - c0);
+        for (int k = tid; k < m; k += kLossThreads) {
+            const int c = c0 + k;
+            const int32_t ai = a.arrival[eoff + c];
+            const int32_t arr_i = ai < 0 ? a.steps : ai;
+            const double arr = (double)arr_i;
+            const double pk = (double)a.peak[eoff + c];
+            if (a.arrival_out) a.arrival_out[(size_t)e * a.n + c] = arr_i;
+            if (a.peak_out) a.peak_out[(size_t)e * a.n + c] = pk;
+            if (a.loss) {
+                const double da = arr - (a.has_arrive[c] ? a.t_arrive[c] : arr);
+                const double dp = pk - (a.has_peak[c] ? a.t_peak[c] : pk);
+                sh_qa[k] = da * da;
+                sh_qp[k] = dp * dp;
+            }
+        }
+        if (a.loss == nullptr) continue;
+        __syncthreads();
+        if (tid == 0 || tid == 64) {
+            const double* q = tid == 0 ? sh_qa : sh_qp;
+            int k = 0;
+            if (c0 == 0) { sum = q[0]; k = 1; }
+            for (; k < m; ++k) sum = sum + q[k];
+        }
+        __syncthreads();
     }
-    if (lane != 0 || a.loss == nullptr) return;
-    double sa = 0.0, sp = 0.0;
-    for (int c = 0; c < a.n; ++c) {
-        const double arr = (double)(a.arrival[eoff + c] < 0 ? a.steps : a.arrival[eoff + c]);
-        const double pk = (double)a.peak[eoff + c];
-        const double da = arr - (a.has_arrive[c] ? a.t_arrive[c] : arr);
-        const double dp = pk - (a.has_peak[c] ? a.t_peak[c] : pk);
-        const double qa = da * da, qp = dp * dp;
-        sa = (c == 0) ? qa : sa + qa;
-        sp = (c == 0) ? qp : sp + qp;
-    }
+    if (a.loss == nullptr) return;
+    if (tid == 64) sh_sp = sum;
+    __syncthreads();
+    if (tid != 0) return;
+    const double sa = sum, sp = sh_sp;
     const double nn = fmax(1.0, (double)a.n);
     const double arr_loss = sqrt(sa / nn);
     const double pk_loss = sqrt(sp / nn);
@@ -1187,7 +1233,7 @@ __global__ __launch_bounds__(64) void loss_kernel(const LossArgs a) {
 
 hipError_t launch_loss(const LossArgs& a, hipStream_t s) {
     if (a.count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(loss_kernel, dim3((unsigned)a.count), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(loss_kernel, dim3((unsigned)a.count), dim3(kLossThreads), 0, s, a);
     return hipGetLastError();
 }
 

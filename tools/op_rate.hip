@@ -1,5 +1,6 @@
 // Issue rate of single vector instructions the apportionment's key computation uses (wave-instructions per
-// cycle and SIMD, from a long dependent-free stream): v_mul_f64, v_fract_f64, v_cvt_i32_f64, v_add_u32.
+// cycle and SIMD, from a long dependent-free stream): v_mul_f64, v_fract_f64, v_cvt_i32_f64, v_add_u32, and the
+// instructions of a double-precision division (EpidemicEnv.step divides seven times per country and day).
 //   hipcc -O3 --offload-arch=gfx950 tools/op_rate.hip -o tools/op_rate && tools/op_rate
 #include <hip/hip_runtime.h>
 
@@ -19,6 +20,14 @@ __global__ void __launch_bounds__(256) op_kernel(double* out, int iters) {
             if (OP == 2) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(w[u]) : "v"(v[u]));
             if (OP == 3) asm volatile("v_add_u32 %0, %0, %1" : "+v"(w[u]) : "v"(w[(u + 1) & 7]));
             if (OP == 4) asm volatile("v_add_f64 %0, %0, %1" : "+v"(v[u]) : "v"(v[(u + 1) & 7]));
+            if (OP == 6) asm volatile("v_rcp_f64 %0, %1" : "=v"(v[u]) : "v"(v[(u + 1) & 7]));
+            if (OP == 7) asm volatile("v_div_scale_f64 %0, vcc, %1, %1, %2" : "=v"(v[u]) : "v"(v[(u + 1) & 7]), "v"(v[(u + 2) & 7]) : "vcc");
+            if (OP == 8) asm volatile("v_div_fmas_f64 %0, %0, %1, %2" : "+v"(v[u]) : "v"(v[(u + 1) & 7]), "v"(v[(u + 2) & 7]) : "vcc");
+            if (OP == 9) asm volatile("v_div_fixup_f64 %0, %0, %1, %2" : "+v"(v[u]) : "v"(v[(u + 1) & 7]), "v"(v[(u + 2) & 7]));
+            if (OP == 10) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v[u]) : "v"(v[(u + 1) & 7]), "v"(v[(u + 2) & 7]));
+            if (OP == 11) asm volatile("v_floor_f64 %0, %1" : "=v"(v[u]) : "v"(v[(u + 1) & 7]));
+            if (OP == 12) asm volatile("v_max_f64 %0, %0, %1" : "+v"(v[u]) : "v"(v[(u + 1) & 7]));
+            if (OP == 13) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(v[u]) : "v"(w[u]));
             if (OP == 5) asm volatile("v_cmp_ge_u32 vcc, %0, %1\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(w[u]) : "v"(w[(u + 1) & 7]) : "vcc");
         }
     }
@@ -55,5 +64,13 @@ int main() {
     run<1>("v_fract_f64", out, 1);
     run<2>("v_cvt_i32_f64", out, 1);
     run<5>("v_cmp + v_addc", out, 2);
+    run<10>("v_fma_f64", out, 1);
+    run<6>("v_rcp_f64", out, 1);
+    run<7>("v_div_scale_f64", out, 1);
+    run<8>("v_div_fmas_f64", out, 1);
+    run<9>("v_div_fixup_f64", out, 1);
+    run<11>("v_floor_f64", out, 1);
+    run<12>("v_max_f64", out, 1);
+    run<13>("v_cvt_f64_i32", out, 1);
     return 0;
 }
