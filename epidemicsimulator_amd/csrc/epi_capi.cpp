@@ -119,6 +119,17 @@ struct GraphTables {
     std::vector<int32_t> h_rowptr, h_col;
     std::vector<double> h_val;
     std::vector<double> h_ell_q;          // host copy of the ELL weights (seed-block variants are cut from it)
+    // A sweep numbers the patches of a sparse graph in lane-layout order inside the engine (renumbered): internal id
+    // p < n_ell is the row at position p of the length-sorted blocks, the long rows follow.  A block of 64 rows is then
+    // 64 consecutive patches: the mobility phase reads the exports and the local phase writes them with coalesced
+    // accesses, and no second, position-ordered copy of the exports exists.  id_of[c] = internal id of the caller's
+    // patch c, orig_of = its inverse; both empty when the numbering is the caller's.
+    bool renumbered = false;
+    int n_ell = 0;
+    std::vector<int32_t> id_of, orig_of;
+    DevBuf d_id_of;
+    int inner(int c) const { return renumbered ? id_of[(size_t)c] : c; }
+    int outer(int p) const { return renumbered && p >= 0 && p < n ? orig_of[(size_t)p] : p; }
 
     // Normalises one stored row in column order: the reference sums the full row left to right, and
     // adding the zeros of the entries that are not stored changes no partial sum.
@@ -140,7 +151,7 @@ struct GraphTables {
     }
 
     int32_t build_sparse(const int32_t* pop_, const double* conn, const int32_t* rowptr, const int32_t* col,
-                         const double* val) {
+                         const double* val, bool renumber) {
         sparse = true;
         npad = (n + 63) / 64 * 64;
         if (csr_lds_bytes(n) > kMaxLdsBytes)
@@ -177,11 +188,8 @@ struct GraphTables {
             int32_t rc = normalise_sparse_row(h_val.data() + rs, h_col.data() + rs, deg, i, hq.data() + rs, &hs[i]);
             if (rc) return rc;
         }
-        std::vector<int32_t> hp((size_t)npad, 0);
-        for (int c = 0; c < n; ++c) {
+        for (int c = 0; c < n; ++c)
             if (pop_[c] < 0) return fail(EPI_ERR_BAD_ARGUMENT, "pop[%d] = %d is negative", c, pop_[c]);
-            hp[c] = pop_[c];
-        }
         // Slot-major blocks of 64 rows: one lane per row reads its k-th weight with a coalesced load.  The rows
         // a lane can hold are sorted by length, longest first, before they are cut into blocks: a block then
         // stores (and the kernel reads and sorts) about as many slots as its rows really have, and the work
@@ -195,6 +203,22 @@ struct GraphTables {
         std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
             return h_rowptr[x + 1] - h_rowptr[x] > h_rowptr[y + 1] - h_rowptr[y];
         });
+        n_ell = (int)order.size();
+        renumbered = renumber;
+        id_of.clear(); orig_of.clear();
+        if (renumbered) {
+            id_of.assign((size_t)n, 0);
+            orig_of.assign((size_t)n, 0);
+            for (size_t p = 0; p < order.size(); ++p) id_of[(size_t)order[p]] = (int32_t)p;
+            for (size_t o = 0; o < h_long_rows.size(); ++o) id_of[(size_t)h_long_rows[o]] = (int32_t)(n_ell + (int)o);
+            for (int c = 0; c < n; ++c) orig_of[(size_t)id_of[(size_t)c]] = c;
+        }
+        std::vector<int32_t> hp((size_t)npad, 0);
+        std::vector<double> hs_in((size_t)npad, 0.0);   // row sums and populations in the engine's numbering
+        for (int c = 0; c < n; ++c) {
+            hp[(size_t)inner(c)] = pop_[c];
+            hs_in[(size_t)inner(c)] = hs[(size_t)c];
+        }
         const int nblocks = ((int)order.size() + 63) / 64;
         n_blocks = nblocks;
         h_slots.assign((size_t)(nblocks > 0 ? nblocks : 1), 0);
@@ -222,11 +246,12 @@ struct GraphTables {
             const int i = order[p], b = (int)(p / 64), l = (int)(p % 64), rs = h_rowptr[i], deg = h_rowptr[i + 1] - rs;
             for (int k = 0; k < deg; ++k) {
                 eq[((size_t)h_off[b] + k) * 64 + l] = hq[rs + k];
-                ec[((size_t)h_off[b] + k) * 64 + l] = h_col[rs + k];
+                ec[((size_t)h_off[b] + k) * 64 + l] = inner(h_col[rs + k]);   // slots stay in the caller's column order
             }
         }
         const size_t nl = h_long_rows.size();
-        std::vector<int32_t> lr(h_long_rows), lo(nl ? nl : 1, 0);
+        std::vector<int32_t> lr(nl), lo(nl ? nl : 1, 0);
+        for (size_t o = 0; o < nl; ++o) lr[o] = inner(h_long_rows[o]);
         size_t long_elems = 0;
         for (size_t o = 0; o < nl; ++o) {
             const int i = h_long_rows[o];
@@ -237,28 +262,39 @@ struct GraphTables {
         std::vector<int32_t> lc(long_elems ? long_elems : 64, -1);
         for (size_t o = 0; o < nl; ++o) {
             const int i = h_long_rows[o], rs = h_rowptr[i], deg = h_rowptr[i + 1] - rs;
-            for (int k = 0; k < deg; ++k) { lq[(size_t)lo[o] + k] = hq[rs + k]; lc[(size_t)lo[o] + k] = h_col[rs + k]; }
+            for (int k = 0; k < deg; ++k) { lq[(size_t)lo[o] + k] = hq[rs + k]; lc[(size_t)lo[o] + k] = inner(h_col[rs + k]); }
         }
         if (lr.empty()) lr.push_back(0);
         HIP_TRY(d_long_off.upload(lo));
         HIP_TRY(d_long_rows.upload(lr));
         HIP_TRY(d_long_q.upload(lq));
         HIP_TRY(d_long_col.upload(lc));
-        HIP_TRY(d_rowptr.upload(h_rowptr));
+        {   // row lengths in the engine's numbering (the kernel reads them for the long rows)
+            std::vector<int32_t> rp((size_t)n + 1, 0);
+            for (int c = 0; c < n; ++c) rp[(size_t)inner(c) + 1] = h_rowptr[c + 1] - h_rowptr[c];
+            for (int p = 0; p < n; ++p) rp[(size_t)p + 1] += rp[(size_t)p];
+            HIP_TRY(d_rowptr.upload(rp));
+        }
         std::vector<EllBlock> hb(h_slots.size());
         for (size_t b = 0; b < hb.size(); ++b) {
             hb[b].slots = h_slots[b];
             hb[b].off = h_off[b];
         }
         HIP_TRY(d_ell.upload(hb));
-        HIP_TRY(d_ell_rows.upload(rows));
-        std::vector<int32_t> pos_pad((size_t)npad, -1);
-        std::copy(h_pos.begin(), h_pos.end(), pos_pad.begin());
-        HIP_TRY(d_ell_pos.upload(pos_pad));
+        if (renumbered) {
+            d_ell_rows.release();
+            d_ell_pos.release();
+            HIP_TRY(d_id_of.upload(id_of));
+        } else {
+            HIP_TRY(d_ell_rows.upload(rows));
+            std::vector<int32_t> pos_pad((size_t)npad, -1);
+            std::copy(h_pos.begin(), h_pos.end(), pos_pad.begin());
+            HIP_TRY(d_ell_pos.upload(pos_pad));
+        }
         HIP_TRY(d_col.upload(ec));
         HIP_TRY(d_qval.upload(eq));
         h_ell_q.swap(eq);
-        HIP_TRY(sumw.upload(hs));
+        HIP_TRY(sumw.upload(hs_in));
         HIP_TRY(pop.upload(hp));
         return EPI_OK;
     }
@@ -268,8 +304,11 @@ struct GraphTables {
         if (sparse) {
             ea.q = nullptr; ea.qtop = nullptr;
             ea.rowptr = d_rowptr.as<int32_t>(); ea.col = d_col.as<int32_t>(); ea.qval = d_qval.as<double>();
-            ea.ell = d_ell.as<EllBlock>(); ea.ell_rows = d_ell_rows.as<int32_t>(); ea.ell_pos = d_ell_pos.as<int32_t>();
+            ea.ell = d_ell.as<EllBlock>();
+            ea.ell_rows = renumbered ? nullptr : d_ell_rows.as<int32_t>();
+            ea.ell_pos = renumbered ? nullptr : d_ell_pos.as<int32_t>();
             ea.n_blocks = n_blocks;
+            ea.n_ell = n_ell;
             ea.seed_block = -1;
             ea.max_deg = lane_deg;
             ea.n_long = (int)h_long_rows.size();
@@ -281,9 +320,9 @@ struct GraphTables {
     }
 
     int32_t build(int n_, const int32_t* pop_, const double* conn, const int32_t* rowptr, const int32_t* col,
-                  const double* val) {
+                  const double* val, bool renumber = false) {
         n = n_;
-        if (n > kMaxDenseN) return build_sparse(pop_, conn, rowptr, col, val);
+        if (n > kMaxDenseN) return build_sparse(pop_, conn, rowptr, col, val, renumber);
         npad = dense_slots_for(n) * 64;
         int32_t rc = densify(n, conn, rowptr, col, val, W);
         if (rc) return rc;
@@ -438,13 +477,14 @@ const char* status_text(int code) {
 }
 
 // First failing episode of a run, from the device error table.
-int32_t collect_errors(const int32_t* err, int count, int g_begin, int g_stride = 1) {
+// `graph` (optional) turns the engine's patch numbers back into the caller's.
+int32_t collect_errors(const int32_t* err, int count, int g_begin, int g_stride = 1, const GraphTables* graph = nullptr) {
     std::vector<int32_t> h((size_t)count * 4);
     HIP_TRY(hipMemcpy(h.data(), err, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (int e = 0; e < count; ++e)
         if (h[(size_t)e * 4] != 0)
             return fail(h[(size_t)e * 4], "%s (instance %d, country %d, t=%d)", status_text(h[(size_t)e * 4]), g_begin + e * g_stride,
-                        h[(size_t)e * 4 + 1], h[(size_t)e * 4 + 2]);
+                        graph ? graph->outer(h[(size_t)e * 4 + 1]) : h[(size_t)e * 4 + 1], h[(size_t)e * 4 + 2]);
     return EPI_OK;
 }
 
@@ -756,10 +796,14 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
     G->device = d->device;
     G->n = d->n; G->steps = d->steps; G->n_beta = d->n_beta; G->n_travel = d->n_travel; G->seed_idx = d->seed_idx;
     G->base = d->base;
-    rc = G->graph.build(d->n, d->pop, d->conn, d->csr_rowptr, d->csr_col, d->csr_val);
+    // a sparse graph is renumbered inside the engine (GraphTables::renumbered): every per-country table below is
+    // filed under in(c), and the loss kernel reads arrival / peak back through the same map
+    rc = G->graph.build(d->n, d->pop, d->conn, d->csr_rowptr, d->csr_col, d->csr_val, true);
     if (rc) return rc;
     const int n = d->n, npad = G->graph.npad;
     G->npad = npad;
+    auto in = [&](int c) { return (size_t)G->graph.inner(c); };
+    G->seed_idx = (int)in(d->seed_idx);
 
     // seed-row variants: ToyConn.scaleRow(W, seedIdx, ts) touches only that row (Calibrate.scala:29)
     if (G->graph.sparse) {
@@ -847,19 +891,19 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
                 e.base_beta = d->heterogeneous
                                   ? beta * (1.0 + (p.population_density / 1000.0) * 0.5) * (3.0 - p.healthcare_capacity * 2.0)
                                   : beta;
-                hb[(size_t)b * npad + c] = make_step_consts(e, p).beta0;
+                hb[(size_t)b * npad + in(c)] = make_step_consts(e, p).beta0;
             }
             e.base_beta = 0.0;
             const StepConsts sc = make_step_consts(e, p);
-            hc[(size_t)CST_GAMMA * npad + c] = sc.gamma;
-            hc[(size_t)CST_IFR0 * npad + c] = sc.ifr0;
-            hc[(size_t)CST_CNOISE * npad + c] = sc.cnoise;
-            hc[(size_t)CST_EFF1 * npad + c] = sc.eff1;
-            hc[(size_t)CST_EFF2 * npad + c] = sc.eff2;
-            hc[(size_t)CST_EFF3 * npad + c] = sc.eff3;
-            hc[(size_t)CST_SURGE * npad + c] = sc.surge;
-            hc[(size_t)CST_VAX6 * npad + c] = sc.vax6;
-            hc[(size_t)CST_VAX7 * npad + c] = sc.vax7;
+            hc[(size_t)CST_GAMMA * npad + in(c)] = sc.gamma;
+            hc[(size_t)CST_IFR0 * npad + in(c)] = sc.ifr0;
+            hc[(size_t)CST_CNOISE * npad + in(c)] = sc.cnoise;
+            hc[(size_t)CST_EFF1 * npad + in(c)] = sc.eff1;
+            hc[(size_t)CST_EFF2 * npad + in(c)] = sc.eff2;
+            hc[(size_t)CST_EFF3 * npad + in(c)] = sc.eff3;
+            hc[(size_t)CST_SURGE * npad + in(c)] = sc.surge;
+            hc[(size_t)CST_VAX6 * npad + in(c)] = sc.vax6;
+            hc[(size_t)CST_VAX7 * npad + in(c)] = sc.vax7;
         }
         HIP_TRY(G->beta0.upload(hb));
         HIP_TRY(G->cst.upload(hc));
@@ -872,7 +916,7 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
         if (d->heterogeneous) {
             for (int c = 0; c < n; ++c) {
                 JavaRandom r(c + 42);  // Calibrate.scala:36
-                for (int t = 0; t < d->steps; ++t) hz[(size_t)t * npad + c] = r.nextGaussian();
+                for (int t = 0; t < d->steps; ++t) hz[(size_t)t * npad + in(c)] = r.nextGaussian();
             }
         } else {
             JavaRandom r(7);  // Calibrate.scala:32: every env is seeded 7
@@ -1018,7 +1062,7 @@ EPI_API int32_t epi_grid_status(epi_grid* g) {
     HIP_TRY(hipDeviceSynchronize());
     if (!g->pending) return EPI_OK;
     g->pending = false;
-    return collect_errors(g->last_err, g->last_count, g->last_g_begin, g->last_g_stride);
+    return collect_errors(g->last_err, g->last_count, g->last_g_begin, g->last_g_stride, &g->graph);
 }
 
 EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, double* loss, int32_t* arrival, double* peak,
@@ -1110,6 +1154,7 @@ static int32_t grid_enqueue(epi_grid* g, int32_t g_begin, int32_t g_stride, int3
     la.t_arrive = g->t_arrive.as<double>(); la.has_arrive = g->has_arrive.as<uint8_t>();
     la.t_peak = g->t_peak.as<double>(); la.has_peak = g->has_peak.as<uint8_t>();
     la.loss = d_loss; la.arrival_out = d_arr; la.peak_out = d_pk;
+    la.id_of = g->graph.renumbered ? g->graph.d_id_of.as<int32_t>() : nullptr;
     HIP_TRY(launch_loss(la, s));
 
     g->pending = true;

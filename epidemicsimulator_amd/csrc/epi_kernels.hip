@@ -738,7 +738,7 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 p.z = a.noise_episode ? a.noise_episode[eoff + c] : a.noise[(size_t)(t - a.noise_t0) * NP + c];
                 p.cap = a.cap[eoff + c];
                 p.sw = (c == a.seed_idx && a.qval_seed) ? a.sumw_seed[ti] : a.sumw[c];
-                p.pos = a.ell_pos[c];
+                if (a.ell_pos) p.pos = a.ell_pos[c];
             }
             return p;
         };
@@ -838,8 +838,12 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
             int item = grab();
             const int b0 = item < nblocks ? item : 0;
             EllBlock blk = a.ell[b0];
-            int row_n = a.ell_rows[b0 * 64 + lane];
-            int32_t ES = expPS[b0 * 64 + lane], EI = expPI[b0 * 64 + lane];
+            // patches numbered in lane-layout order (ell_rows == NULL): lane l of block b is patch 64 b + l itself
+            const int32_t* __restrict__ expBS = a.ell_rows ? expPS : expS;
+            const int32_t* __restrict__ expBI = a.ell_rows ? expPI : expI;
+            auto row_of = [&](int pos) { return a.ell_rows ? a.ell_rows[pos] : (pos < a.n_ell ? pos : -1); };
+            int row_n = row_of(b0 * 64 + lane);
+            int32_t ES = expBS[b0 * 64 + lane], EI = expBI[b0 * 64 + lane];
             while (item < nitems) {
                 const int next = grab();
                 if (item < nblocks) {
@@ -850,9 +854,9 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                     {
                         const int bn = next < nblocks ? next : b;
                         blk = a.ell[bn];
-                        row_n = a.ell_rows[bn * 64 + lane];
-                        ES = expPS[bn * 64 + lane];
-                        EI = expPI[bn * 64 + lane];
+                        row_n = row_of(bn * 64 + lane);
+                        ES = expBS[bn * 64 + lane];
+                        EI = expBI[bn * 64 + lane];
                     }
                     const int D = __builtin_amdgcn_readfirstlane(cur.slots);  // same for the whole block
                     if (__any((ESc | EIc) != 0) && D > 0) {
@@ -1197,10 +1201,11 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(const LossArgs a) {
         const int m = min(kLossChunk, a.n - c0);
         for (int k = tid; k < m; k += kLossThreads) {
             const int c = c0 + k;
-            const int32_t ai = a.arrival[eoff + c];
+            const int ci = a.id_of ? a.id_of[c] : c;
+            const int32_t ai = a.arrival[eoff + ci];
             const int32_t arr_i = ai < 0 ? a.steps : ai;
             const double arr = (double)arr_i;
-            const double pk = (double)a.peak[eoff + c];
+            const double pk = (double)a.peak[eoff + ci];
             if (a.arrival_out) a.arrival_out[(size_t)e * a.n + c] = arr_i;
             if (a.peak_out) a.peak_out[(size_t)e * a.n + c] = pk;
             if (a.loss) {

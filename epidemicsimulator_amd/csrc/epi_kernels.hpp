@@ -47,6 +47,8 @@ struct EpisodeArgs {
     const int32_t* ell_rows;  // [n_blocks][64] row of each lane, -1 = no row
     const int32_t* ell_pos;   // [npad] inverse: position 64*b + l of a row in the lane layout, -1 = long row
     int n_blocks;
+    int n_ell;                // rows held in the blocks; with ell_rows == ell_pos == NULL row 64*b + l IS patch 64*b + l (patches numbered
+                              // in lane-layout order, long rows last): no second copy of the exports, no scattered stores
     int seed_block;           // block that holds the seed row, -1 if it is a long row (or there are no variants)
     const int32_t* col;       // ELL columns, ascending inside a row, -1 = padding; every block occupies a whole
                               // number of slot groups (kSlotGroup), the extra slots holding weight 0
@@ -113,6 +115,7 @@ struct LossArgs {
     const int32_t* arrival; const int32_t* peak;
     const double* t_arrive; const uint8_t* has_arrive; const double* t_peak; const uint8_t* has_peak;
     double* loss; int32_t* arrival_out; double* peak_out;  // arrival_out/peak_out [count][n] optional
+    const int32_t* id_of;  // optional [n]: arrival / peak hold country c at index id_of[c] (engine-internal numbering)
 };
 
 // One network of DDQNAgent (MLP.scala:4-13: 7 -> H -> H -> 8) in device memory, every matrix with row stride Hp
