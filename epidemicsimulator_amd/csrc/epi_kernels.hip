@@ -1395,6 +1395,188 @@ __global__ __launch_bounds__(256) void mlp_greedy_kernel(const MlpArgs a) {
     }
 }
 
+// The same evaluation for large batches that share a network (the argmax-Q step of a sweep: every patch of every
+// episode).  One wave per workgroup evaluates 32 states as four tiles of 8: lane (g, q), g = lane / 16, q = lane % 16,
+// owns the UN = HP / 16 hidden units q * UN .. q * UN + UN - 1 for the 8 states of tile g.  Per input k of the second
+// layer a lane reads its tile's 8 activations (four 16-byte LDS reads, the same address in all 16 lanes of the tile)
+// and its UN weights (global, the same in all four tiles) for 8 * UN multiply-add pairs: the layer is bound by the
+// vector unit, where the unit-per-thread kernel above is bound by the LDS return path (16 reads per 32 operations).
+// Every sum runs over k in ascending order with a separate multiply and add, as in mlp_greedy_kernel.
+// HP = hidden units = row stride of the network image (64 or 128).
+constexpr int MLP_TILE_ROWS = 32;
+
+template <int HP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void mlp_tile_kernel(const MlpArgs a) {
+    constexpr int UN = HP / 16;     // units per lane
+    constexpr int TM = 8;           // states per tile
+    constexpr int KB = 2;           // inputs whose weights are fetched together
+    __shared__ __align__(16) double sh_x[MLP_TILE_ROWS][8];
+    __shared__ __align__(16) double sh_h[HP][MLP_TILE_ROWS];   // activations, input-major: [k][state]
+    __shared__ __align__(16) double sh_y[MLP_TILE_ROWS][8];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, q = lane & 15;
+    const int cfix = a.per_country ? (int)blockIdx.y : 0;
+    const double* __restrict__ net = a.nets + (a.per_country ? (size_t)cfix * a.net_stride : 0);
+    const NetLayout nl{HP, HP};
+    auto locate = [&](int r, int& e, int& c) {
+        if (a.per_country) {
+            e = blockIdx.x * MLP_TILE_ROWS + r;
+            c = cfix;
+            return e < a.count;
+        }
+        const int row = blockIdx.x * MLP_TILE_ROWS + r;
+        e = row / a.n;
+        c = row - e * a.n;
+        return row < a.rows;
+    };
+    if (lane < MLP_TILE_ROWS) {
+        double f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int e, c;
+        if (locate(lane, e, c)) {
+            double s, i, r, d, v, cap;
+            int32_t t, tmax;
+            if (a.st) {
+                const size_t idx = (size_t)e * a.npad + c;
+                s = (double)a.st[0 * a.plane + idx]; i = (double)a.st[1 * a.plane + idx];
+                r = (double)a.st[2 * a.plane + idx]; d = (double)a.st[3 * a.plane + idx];
+                v = (double)a.st[4 * a.plane + idx];
+                cap = a.cap[idx]; t = a.tcur[idx]; tmax = a.state_t_max;
+            } else {
+                const epi_state& st = a.states[(size_t)e * a.n + c];
+                s = st.s; i = st.i; r = st.r; d = st.d; v = st.v; cap = st.hosp_cap; t = st.t; tmax = st.t_max;
+            }
+            const double N = fmax(1.0, s + i + r + d);
+            f[0] = s / N; f[1] = i / N; f[2] = r / N; f[3] = d / N; f[4] = v / N;
+            f[5] = i / fmax(1.0, cap);
+            f[6] = (double)t / (double)(tmax > 1 ? tmax : 1);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sh_x[lane][k] = f[k];
+    }
+    const int u0 = q * UN;
+    const double* __restrict__ W2T = net + nl.w2t() + u0;
+    // the first weights of the second layer are on their way while the first layer is computed
+    double wn[KB][UN];
+#pragma unroll
+    for (int j = 0; j < KB; ++j)
+#pragma unroll
+        for (int u = 0; u < UN; ++u) wn[j][u] = W2T[(size_t)j * HP + u];
+    __syncthreads();
+    {   // first layer: UN units x TM states per lane
+        double w[7][UN], b[UN];
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int u = 0; u < UN; ++u) w[k][u] = net[nl.w1t() + (size_t)k * HP + u0 + u];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) b[u] = net[nl.b1() + u0 + u];
+#pragma unroll
+        for (int r = 0; r < TM; ++r) {
+            double x[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) x[k] = sh_x[g * TM + r][k];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                double acc = w[0][u] * x[0];
+#pragma unroll
+                for (int k = 1; k < 7; ++k) acc = acc + w[k][u] * x[k];
+                const double z = acc + b[u];
+                sh_h[u0 + u][g * TM + r] = z > 0 ? z : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+    double acc[UN][TM];
+    // one batch of KB inputs: `first` starts the sums with the product of input 0 (no addition to a zero)
+    auto batch = [&](int k0, auto first) {
+        double wc[KB][UN];
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+#pragma unroll
+            for (int u = 0; u < UN; ++u) wc[j][u] = wn[j][u];
+        if (k0 + KB < HP) {
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+#pragma unroll
+                for (int u = 0; u < UN; ++u) wn[j][u] = W2T[(size_t)(k0 + KB + j) * HP + u];
+        }
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            double h[TM];
+#pragma unroll
+            for (int r = 0; r < TM; ++r) h[r] = sh_h[k0 + j][g * TM + r];
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                for (int r = 0; r < TM; ++r) {
+                    const double p = wc[j][u] * h[r];
+                    if (decltype(first)::value && j == 0) acc[u][r] = p;
+                    else acc[u][r] = acc[u][r] + p;
+                }
+        }
+    };
+    batch(0, std::true_type{});
+#pragma nounroll
+    for (int k0 = KB; k0 < HP; k0 += KB) batch(k0, std::false_type{});
+    __syncthreads();   // every lane has read the first layer's activations: the buffer takes the second layer's
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        const double b = net[nl.b2() + u0 + u];
+#pragma unroll
+        for (int r = 0; r < TM; ++r) {
+            const double z = acc[u][r] + b;
+            sh_h[u0 + u][g * TM + r] = z > 0 ? z : 0.0;
+        }
+    }
+    __syncthreads();
+    {   // third layer: lane = (state, four of the eight outputs)
+        const int row = lane & 31, o0 = (lane >> 5) * 4;
+        double y[4];
+        const double* __restrict__ W3 = net + nl.w3() + (size_t)o0 * HP;
+        auto batch3 = [&](int k0, auto first) {
+            double w[4][8], h[8];
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[o][j] = W3[(size_t)o * HP + k0 + j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = sh_h[k0 + j][row];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const double p = w[o][j] * h[j];
+                    if (decltype(first)::value && j == 0) y[o] = p;
+                    else y[o] = y[o] + p;
+                }
+        };
+        batch3(0, std::true_type{});
+#pragma nounroll
+        for (int k0 = 8; k0 < HP; k0 += 8) batch3(k0, std::false_type{});
+        const double clip = a.clip_ptr ? a.clip_ptr[(size_t)cfix * a.clip_stride] : a.clip_q;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            double v = y[o] + net[nl.b3() + o0 + o];
+            if (isfinite(clip)) v = fmax(-clip, fmin(clip, v));
+            sh_y[row][o0 + o] = v;
+        }
+    }
+    __syncthreads();
+    if (lane < MLP_TILE_ROWS) {
+        int e, c;
+        if (locate(lane, e, c)) {
+            const size_t row = (size_t)e * a.n + c;
+            int best = 0;
+            for (int o = 1; o < 8; ++o)
+                if (sh_y[lane][o] > sh_y[lane][best]) best = o;
+            if (a.act_episode) a.act_episode[(size_t)e * a.npad + c] = (int8_t)best;
+            if (a.act_out) a.act_out[row] = best;
+            if (a.q_out)
+                for (int o = 0; o < 8; ++o) a.q_out[row * 8 + o] = sh_y[lane][o];
+        }
+    }
+}
+
 template <int ROWS>
 static hipError_t launch_mlp_rows(const MlpArgs& a, int live, hipStream_t s) {
     const int H = a.nl.H;
@@ -1414,6 +1596,12 @@ hipError_t launch_mlp(const MlpArgs& a, hipStream_t s) {
     const int H = a.nl.H;
     if (H < 1 || H > MLP_MAXH || a.nl.Hp < H || a.nl.Hp % 64 != 0) return hipErrorInvalidValue;
     const int live = a.per_country ? a.count : a.rows;   // states that share a network
+    if (live >= 4 * MLP_TILE_ROWS && H == a.nl.Hp && (H == 64 || H == 128)) {   // a large batch on one network
+        const dim3 grid((unsigned)((live + MLP_TILE_ROWS - 1) / MLP_TILE_ROWS), a.per_country ? (unsigned)a.n : 1u);
+        if (H == 64) hipLaunchKernelGGL(mlp_tile_kernel<64>, grid, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(mlp_tile_kernel<128>, grid, dim3(64), 0, s, a);
+        return hipGetLastError();
+    }
     if (live <= 1) return launch_mlp_rows<1>(a, live, s);
     if (live <= 2) return launch_mlp_rows<2>(a, live, s);
     if (live <= 4) return launch_mlp_rows<4>(a, live, s);
