@@ -1396,25 +1396,27 @@ __global__ __launch_bounds__(256) void mlp_greedy_kernel(const MlpArgs a) {
 }
 
 // The same evaluation for large batches that share a network (the argmax-Q step of a sweep: every patch of every
-// episode).  One wave per workgroup evaluates 32 states as four tiles of 8: lane (g, q), g = lane / 16, q = lane % 16,
-// owns the UN = HP / 16 hidden units q * UN .. q * UN + UN - 1 for the 8 states of tile g.  Per input k of the second
-// layer a lane reads its tile's 8 activations (four 16-byte LDS reads, the same address in all 16 lanes of the tile)
-// and its UN weights (global, the same in all four tiles) for 8 * UN multiply-add pairs: the layer is bound by the
-// vector unit, where the unit-per-thread kernel above is bound by the LDS return path (16 reads per 32 operations).
-// Every sum runs over k in ascending order with a separate multiply and add, as in mlp_greedy_kernel.
+// episode).  A workgroup of two waves evaluates 32 states as four tiles of 8: thread (w, g, q) -- wave w, g = lane / 16,
+// q = lane % 16 -- owns the UN = HP / 32 hidden units (16 w + q) * UN .. + UN - 1 for the 8 states of tile g.  Per input k
+// of the second layer a lane reads its tile's 8 activations (four 16-byte LDS reads, the same address in all 16 lanes
+// of the tile) and its UN weights (global, the same in all four tiles) for 8 * UN multiply-add pairs: the layer is
+// bound by the vector unit, where the unit-per-thread kernel above is bound by the LDS return path (16 reads per 32
+// operations).  Every sum runs over k in ascending order with a separate multiply and add, as in mlp_greedy_kernel.
 // HP = hidden units = row stride of the network image (64 or 128).
 constexpr int MLP_TILE_ROWS = 32;
+constexpr int MLP_TILE_THREADS = 128;
 
 template <int HP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void mlp_tile_kernel(const MlpArgs a) {
-    constexpr int UN = HP / 16;     // units per lane
+__global__ __launch_bounds__(MLP_TILE_THREADS) void mlp_tile_kernel(const MlpArgs a) {
+    constexpr int UN = HP / 32;     // units per thread
     constexpr int TM = 8;           // states per tile
-    constexpr int KB = 2;           // inputs whose weights are fetched together
+    constexpr int KB = 4;           // inputs whose weights are fetched together
     __shared__ __align__(16) double sh_x[MLP_TILE_ROWS][8];
     __shared__ __align__(16) double sh_h[HP][MLP_TILE_ROWS];   // activations, input-major: [k][state]
     __shared__ __align__(16) double sh_y[MLP_TILE_ROWS][8];
-    const int lane = threadIdx.x;
-    const int g = lane >> 4, q = lane & 15;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int g = lane >> 4;
     const int cfix = a.per_country ? (int)blockIdx.y : 0;
     const double* __restrict__ net = a.nets + (a.per_country ? (size_t)cfix * a.net_stride : 0);
     const NetLayout nl{HP, HP};
@@ -1429,10 +1431,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         c = row - e * a.n;
         return row < a.rows;
     };
-    if (lane < MLP_TILE_ROWS) {
+    if (tid < MLP_TILE_ROWS) {
         double f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int e, c;
-        if (locate(lane, e, c)) {
+        if (locate(tid, e, c)) {
             double s, i, r, d, v, cap;
             int32_t t, tmax;
             if (a.st) {
@@ -1451,9 +1453,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
             f[6] = (double)t / (double)(tmax > 1 ? tmax : 1);
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) sh_x[lane][k] = f[k];
+        for (int k = 0; k < 8; ++k) sh_x[tid][k] = f[k];
     }
-    const int u0 = q * UN;
+    const int u0 = ((tid >> 6) * 16 + (lane & 15)) * UN;
     const double* __restrict__ W2T = net + nl.w2t() + u0;
     // the first weights of the second layer are on their way while the first layer is computed
     double wn[KB][UN];
@@ -1462,7 +1464,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 #pragma unroll
         for (int u = 0; u < UN; ++u) wn[j][u] = W2T[(size_t)j * HP + u];
     __syncthreads();
-    {   // first layer: UN units x TM states per lane
+    {   // first layer: UN units x TM states per thread
         double w[7][UN], b[UN];
 #pragma unroll
         for (int k = 0; k < 7; ++k)
@@ -1518,7 +1520,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     batch(0, std::true_type{});
 #pragma nounroll
     for (int k0 = KB; k0 < HP; k0 += KB) batch(k0, std::false_type{});
-    __syncthreads();   // every lane has read the first layer's activations: the buffer takes the second layer's
+    __syncthreads();   // every thread has read the first layer's activations: the buffer takes the second layer's
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
         const double b = net[nl.b2() + u0 + u];
@@ -1529,14 +1531,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         }
     }
     __syncthreads();
-    {   // third layer: lane = (state, four of the eight outputs)
-        const int row = lane & 31, o0 = (lane >> 5) * 4;
-        double y[4];
+    {   // third layer: thread = (state, two of the eight outputs)
+        const int row = tid & 31, o0 = (tid >> 5) * 2;
+        double y[2];
         const double* __restrict__ W3 = net + nl.w3() + (size_t)o0 * HP;
         auto batch3 = [&](int k0, auto first) {
-            double w[4][8], h[8];
+            double w[2][8], h[8];
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
+            for (int o = 0; o < 2; ++o)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) w[o][j] = W3[(size_t)o * HP + k0 + j];
 #pragma unroll
@@ -1544,7 +1546,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
+                for (int o = 0; o < 2; ++o) {
                     const double p = w[o][j] * h[j];
                     if (decltype(first)::value && j == 0) y[o] = p;
                     else y[o] = y[o] + p;
@@ -1555,24 +1557,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         for (int k0 = 8; k0 < HP; k0 += 8) batch3(k0, std::false_type{});
         const double clip = a.clip_ptr ? a.clip_ptr[(size_t)cfix * a.clip_stride] : a.clip_q;
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
+        for (int o = 0; o < 2; ++o) {
             double v = y[o] + net[nl.b3() + o0 + o];
             if (isfinite(clip)) v = fmax(-clip, fmin(clip, v));
             sh_y[row][o0 + o] = v;
         }
     }
     __syncthreads();
-    if (lane < MLP_TILE_ROWS) {
+    if (tid < MLP_TILE_ROWS) {
         int e, c;
-        if (locate(lane, e, c)) {
+        if (locate(tid, e, c)) {
             const size_t row = (size_t)e * a.n + c;
             int best = 0;
             for (int o = 1; o < 8; ++o)
-                if (sh_y[lane][o] > sh_y[lane][best]) best = o;
+                if (sh_y[tid][o] > sh_y[tid][best]) best = o;
             if (a.act_episode) a.act_episode[(size_t)e * a.npad + c] = (int8_t)best;
             if (a.act_out) a.act_out[row] = best;
             if (a.q_out)
-                for (int o = 0; o < 8; ++o) a.q_out[row * 8 + o] = sh_y[lane][o];
+                for (int o = 0; o < 8; ++o) a.q_out[row * 8 + o] = sh_y[tid][o];
         }
     }
 }
@@ -1598,8 +1600,8 @@ hipError_t launch_mlp(const MlpArgs& a, hipStream_t s) {
     const int live = a.per_country ? a.count : a.rows;   // states that share a network
     if (live >= 4 * MLP_TILE_ROWS && H == a.nl.Hp && (H == 64 || H == 128)) {   // a large batch on one network
         const dim3 grid((unsigned)((live + MLP_TILE_ROWS - 1) / MLP_TILE_ROWS), a.per_country ? (unsigned)a.n : 1u);
-        if (H == 64) hipLaunchKernelGGL(mlp_tile_kernel<64>, grid, dim3(64), 0, s, a);
-        else hipLaunchKernelGGL(mlp_tile_kernel<128>, grid, dim3(64), 0, s, a);
+        if (H == 64) hipLaunchKernelGGL(mlp_tile_kernel<64>, grid, dim3(MLP_TILE_THREADS), 0, s, a);
+        else hipLaunchKernelGGL(mlp_tile_kernel<128>, grid, dim3(MLP_TILE_THREADS), 0, s, a);
         return hipGetLastError();
     }
     if (live <= 1) return launch_mlp_rows<1>(a, live, s);
