@@ -316,6 +316,15 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(W > R ? 
 // fractions up to a rounding error far below 1, and every fraction is below 1), so the units go
 // to stored entries only; the kernel checks this and reports EPI_ERR_UNSUPPORTED otherwise.
 // ---------------------------------------------------------------------------------------------
+// Inflow accumulators of the sparse kernel: one 8-byte LDS cell per patch, susceptible inflow in the low word and
+// infectious inflow in the high word.  The lane-per-row routine adds both with ONE 64-bit LDS atomic per stored
+// weight (a carry out of the low word would take an inflow of 2^32 people into one patch, which the world mass
+// check reports either way); the wave-per-row routines add to one word at a time through this view.
+struct InflowWords {
+    uint32_t* p;   // word 0 of cell 0
+    __device__ __forceinline__ uint32_t& operator[](int c) const { return p[2 * c]; }
+};
+
 constexpr int kCsrThreads = 768;  // 12 waves, 3 per SIMD: ~170 registers per lane for the keys of two compartments
 
 // Slots are read in groups of kSlotGroup: a group is skipped when the block has no such slots, and all
@@ -416,8 +425,8 @@ __device__ __forceinline__ LaneThreshold lane_threshold(uint32_t (&srt)[DMAX], i
 // A lane that exports nothing in a compartment runs along with E = 0: every product is 0, nothing is selected.
 template <int DMAX>
 __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI, int D, const double* __restrict__ qp,
-                                               const int32_t* __restrict__ cp, int row, uint32_t* sh_movS,
-                                               uint32_t* sh_movI, int* sh_err, int t, long long* tm) {
+                                               const int32_t* __restrict__ cp, int row, unsigned long long* sh_mov,
+                                               int* sh_err, int t, long long* tm) {
     static_assert(DMAX % kSlotGroup == 0, "whole slot groups");
     // slots are worked on in chunks of whole groups: all loads of a chunk are in flight together
     constexpr int HALF = (DMAX % (2 * kSlotGroup) == 0) ? DMAX / 2 : kSlotGroup;
@@ -490,12 +499,12 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
                     uint32_t selS = (uint32_t)((uint32_t)__double2hiint(frac_of(rawS)) >= thS.Kx);
                     if constexpr (kPicked) selS |= (thS.picked >> k) & 1u;
                     const uint32_t allocS = (uint32_t)(int32_t)rawS + selS;
-                    if (allocS != 0u) atomicAdd(&sh_movS[cv[j]], allocS);
                     const double rawI = qv[j] * EdI;
                     uint32_t selI = (uint32_t)((uint32_t)__double2hiint(frac_of(rawI)) >= thI.Kx);
                     if constexpr (kPicked) selI |= (thI.picked >> k) & 1u;
                     const uint32_t allocI = (uint32_t)(int32_t)rawI + selI;
-                    if (allocI != 0u) atomicAdd(&sh_movI[cv[j]], allocI);
+                    if ((allocS | allocI) != 0u)
+                        atomicAdd(&sh_mov[cv[j]], (unsigned long long)allocS | ((unsigned long long)allocI << 32));
                 }
             }
         }
@@ -511,14 +520,14 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
 // high word finished on the low word and then in column order -- only slower: this path exists so that no
 // finite non-negative graph is refused for its row lengths.
 __device__ __noinline__ void wide_row(int32_t ES, int32_t EI, int deg, int row, const double* __restrict__ qrow,
-                                      const int32_t* __restrict__ crow, int lane, uint32_t* sh_movS, uint32_t* sh_movI,
+                                      const int32_t* __restrict__ crow, int lane, InflowWords sh_movS, InflowWords sh_movI,
                                       int* sh_err, int t) {
     const int chunks = (deg + 63) >> 6;
 #pragma nounroll
     for (int comp = 0; comp < 2; ++comp) {
         const int32_t E = comp ? EI : ES;
         if (E <= 0) continue;
-        uint32_t* sh_mov = comp ? sh_movI : sh_movS;
+        const InflowWords sh_mov = comp ? sh_movI : sh_movS;
         const double Ed = (double)E;
         // pass 1: whole units, largest key, number of positive fractions
         uint32_t bsum = 0u, kmax = 0u, pos = 0u;
@@ -629,7 +638,7 @@ __device__ __noinline__ void wide_row(int32_t ES, int32_t EI, int deg, int row, 
 // kernel's routine, S then I, and scatters through the row's column list.
 template <int R>
 __device__ __noinline__ void long_row(int32_t ES, int32_t EI, int deg, int row, const double* __restrict__ qrow,
-                                      const int32_t* __restrict__ crow, int lane, uint32_t* sh_movS, uint32_t* sh_movI) {
+                                      const int32_t* __restrict__ crow, int lane, InflowWords sh_movS, InflowWords sh_movI) {
 #pragma nounroll
     for (int comp = 0; comp < 2; ++comp) {
         const int32_t E = comp ? EI : ES;
@@ -638,7 +647,7 @@ __device__ __noinline__ void long_row(int32_t ES, int32_t EI, int deg, int row, 
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0u;
         apportion_row<R>(E, deg, -1, qrow, acc, lane, nullptr);
-        uint32_t* sh_mov = comp ? sh_movI : sh_movS;
+        const InflowWords sh_mov = comp ? sh_movI : sh_movS;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int col = crow[r * 64 + lane];
@@ -651,8 +660,8 @@ template <int DMAX>
 __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeArgs a) {
     extern __shared__ __align__(16) unsigned char sh_raw[];
     const int n = a.n;
-    uint32_t* sh_movS = reinterpret_cast<uint32_t*>(sh_raw);
-    uint32_t* sh_movI = sh_movS + n;
+    unsigned long long* sh_mov = reinterpret_cast<unsigned long long*>(sh_raw);   // [n] cells {susceptible, infectious}
+    const InflowWords sh_movS{reinterpret_cast<uint32_t*>(sh_raw)}, sh_movI{reinterpret_cast<uint32_t*>(sh_raw) + 1};
     unsigned long long* sh_mass = reinterpret_cast<unsigned long long*>(sh_raw + (((size_t)n * 8 + 15) & ~(size_t)15));
     int* sh_err = reinterpret_cast<int*>(sh_mass + 4);
 
@@ -719,7 +728,8 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
             p.act = 0;
             p.z = p.cap = p.sw = 0.0;
             if (doC) {
-                p.ms = sh_movS[c]; p.mi = sh_movI[c];
+                const unsigned long long cell = sh_mov[c];
+                p.ms = (uint32_t)cell; p.mi = (uint32_t)(cell >> 32);
                 p.es = expS[c]; p.ei = expI[c];
                 p.arr = a.arrival[eoff + c]; p.pk = a.peak[eoff + c];
             }
@@ -793,8 +803,7 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                     expPS[p.pos] = eS;
                     expPI[p.pos] = eI;
                 }
-                sh_movS[c] = 0u;
-                sh_movI[c] = 0u;
+                sh_mov[c] = 0ull;
                 mass_local += ta > 0 ? (unsigned long long)ta : 0ull;
             } else {
                 st_s[c] = s0;
@@ -869,11 +878,11 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                         const bool anyI = __any(EIc > 0);
                         // blocks are sorted by row length: the routine that fits the block's longest row
                         if (DMAX >= 32 && D > 24)
-                            lane_apportion<(DMAX >= 32 ? 32 : DMAX)>(ESc, EIc, anyI, D, qp, cp, row, sh_movS, sh_movI, sh_err, t, tm);
+                            lane_apportion<(DMAX >= 32 ? 32 : DMAX)>(ESc, EIc, anyI, D, qp, cp, row, sh_mov, sh_err, t, tm);
                         else if (DMAX >= 24 && D > 16)
-                            lane_apportion<(DMAX >= 24 ? 24 : DMAX)>(ESc, EIc, anyI, D, qp, cp, row, sh_movS, sh_movI, sh_err, t, tm);
+                            lane_apportion<(DMAX >= 24 ? 24 : DMAX)>(ESc, EIc, anyI, D, qp, cp, row, sh_mov, sh_err, t, tm);
                         else
-                            lane_apportion<16>(ESc, EIc, anyI, D, qp, cp, row, sh_movS, sh_movI, sh_err, t, tm);
+                            lane_apportion<16>(ESc, EIc, anyI, D, qp, cp, row, sh_mov, sh_err, t, tm);
                     }
                 } else {
                     // a row longer than kLaneSlots: one wave with the dense kernel's routine on the compact
