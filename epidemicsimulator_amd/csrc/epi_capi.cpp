@@ -360,6 +360,9 @@ struct EpisodeBuffers {
     int32_t ensure(int count_, int npad_, bool sparse = false) {
         if (count_ <= count && npad_ == npad && (!sparse || exports.p)) return EPI_OK;
         const size_t cells = (size_t)count_ * npad_;
+        if (sparse && cells * 5 * sizeof(int32_t) > 0xffffffffull)  // the sparse kernel reaches a launch's planes through 32-bit byte offsets
+            return fail(EPI_ERR_UNSUPPORTED, "%d instances of %d padded patches in one launch: a sparse world takes at most %zu at a time",
+                        count_, npad_, (size_t)(0xffffffffull / (5 * sizeof(int32_t) * (size_t)npad_)));
         HIP_TRY(st.ensure(cells * 5 * sizeof(int32_t)));
         HIP_TRY(cap.ensure(cells * sizeof(double)));
         HIP_TRY(tcur.ensure(cells * sizeof(int32_t)));

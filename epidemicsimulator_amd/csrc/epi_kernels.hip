@@ -54,6 +54,9 @@ __device__ __forceinline__ void record_error(int* sh_err, int code, int node, in
 #ifndef EPI_KW4
 #define EPI_KW4 16
 #endif
+#ifndef EPI_CSR_KARGS
+#define EPI_CSR_KARGS 1
+#endif
 #ifndef EPI_HIST_MAXR
 #define EPI_HIST_MAXR 8
 #endif
@@ -675,11 +678,6 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
     const int NP = a.npad;
     const size_t eoff = (size_t)e * NP;
     const size_t plane = (size_t)a.count * NP;
-    int32_t* __restrict__ st_s = a.st + 0 * plane + eoff;
-    int32_t* __restrict__ st_i = a.st + 1 * plane + eoff;
-    int32_t* __restrict__ st_r = a.st + 2 * plane + eoff;
-    int32_t* __restrict__ st_d = a.st + 3 * plane + eoff;
-    int32_t* __restrict__ st_v = a.st + 4 * plane + eoff;
     int32_t* __restrict__ expS = a.exports + 0 * plane + eoff;
     int32_t* __restrict__ expI = a.exports + 1 * plane + eoff;
     int32_t* __restrict__ expPS = a.exports + 2 * plane + eoff;  // the same two, indexed by lane-layout position
@@ -697,10 +695,37 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
 #ifndef EPI_CSR_TIMERS
     long long* tm = nullptr;
 #endif
+    // Loads and stores of the local / apply pass: uniform base + 32-bit byte offset of the lane (one launch's planes
+    // stay below 4 GiB, checked at launch), which needs no 64-bit vector arithmetic per access.
+    auto ld4 = [](const int32_t* base, uint32_t off) { return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(base) + off); };
+    auto ld8 = [](const double* base, uint32_t off) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + off); };
+    auto st4 = [](int32_t* base, uint32_t off, int32_t v) { *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(base) + off) = v; };
+    auto st8 = [](double* base, uint32_t off, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + off) = v; };
+#if EPI_CSR_KARGS
+    // The pass reads its arguments again from the kernel-argument segment at every step (scalar loads): held for the
+    // whole kernel next to those of the mobility phase they do not fit the scalar registers.
+    typedef const __attribute__((address_space(4))) EpisodeArgs* KernArgs;
+    const KernArgs kargs = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+#endif
     // Step t: local dynamics (A), barrier, mobility (B), barrier, apply (C).  A thread owns the same patches
     // in A and C, so C of step t-1 and A of step t run as one pass over the thread's patches: the state of a
     // patch is read once and written once per step.
     for (int t = a.t_begin; t <= a.t_end; ++t) {
+#if EPI_CSR_KARGS
+        KernArgs ka = kargs;
+        asm volatile("" : "+s"(ka));
+#else
+        const EpisodeArgs* ka = &a;
+#endif
+        int32_t* const kst = ka->st + eoff;
+        int32_t* const kex = ka->exports + eoff;
+        int32_t* const ktc = ka->tcur + eoff;
+        int32_t* const karr = ka->arrival + eoff;
+        int32_t* const kpk = ka->peak + eoff;
+        double* const kcap = ka->cap + eoff;
+        const double* const kb0 = ka->beta0 + (size_t)bi * NP;
+        const double* const kcst = ka->cst;
+        const uint32_t planeB = (uint32_t)(plane * sizeof(int32_t)), np8 = (uint32_t)NP * 8u;
         const bool doC = t > a.t_begin, doA = t < a.t_end;
         EPI_TM(long long k0 = clock64();)
         if (tid == 0) *sh_next = 0;
@@ -717,11 +742,13 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
         auto fetch = [&](int cc) {
             // the index is made opaque: otherwise one 64-bit address per array is precomputed ahead of the
             // step loop and kept (spilled) for the whole kernel
-            int c = cc;
+            uint32_t c = (uint32_t)cc;
             asm volatile("" : "+v"(c));
+            const uint32_t o4 = c * 4u, o8 = c * 8u;
             PatchIn p;
-            p.s = st_s[c]; p.i = st_i[c]; p.r = st_r[c]; p.d = st_d[c]; p.v = st_v[c];
-            p.tc = a.tcur[eoff + c];
+            p.s = ld4(kst, o4); p.i = ld4(kst, o4 + planeB); p.r = ld4(kst, o4 + 2u * planeB); p.d = ld4(kst, o4 + 3u * planeB);
+            p.v = ld4(kst, o4 + 4u * planeB);
+            p.tc = ld4(ktc, o4);
             p.es = p.ei = p.arr = p.pk = 0;
             p.pos = -1;
             p.ms = p.mi = 0u;
@@ -730,32 +757,33 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
             if (doC) {
                 const unsigned long long cell = sh_mov[c];
                 p.ms = (uint32_t)cell; p.mi = (uint32_t)(cell >> 32);
-                p.es = expS[c]; p.ei = expI[c];
-                p.arr = a.arrival[eoff + c]; p.pk = a.peak[eoff + c];
+                p.es = ld4(kex, o4); p.ei = ld4(kex, o4 + planeB);
+                p.arr = ld4(karr, o4); p.pk = ld4(kpk, o4);
             }
             if (doA) {
-                p.k.beta0 = a.beta0[(size_t)bi * NP + c];
-                p.k.gamma = a.cst[CST_GAMMA * NP + c];
-                p.k.ifr0 = a.cst[CST_IFR0 * NP + c];
-                p.k.cnoise = a.cst[CST_CNOISE * NP + c];
-                p.k.eff1 = a.cst[CST_EFF1 * NP + c];
-                p.k.eff2 = a.cst[CST_EFF2 * NP + c];
-                p.k.eff3 = a.cst[CST_EFF3 * NP + c];
-                p.k.surge = a.cst[CST_SURGE * NP + c];
-                p.k.vax6 = a.cst[CST_VAX6 * NP + c];
-                p.k.vax7 = a.cst[CST_VAX7 * NP + c];
-                p.act = a.act_episode ? (int)a.act_episode[eoff + c] : (int)a.actions[(size_t)(t - a.act_t0) * NP + c];
-                p.z = a.noise_episode ? a.noise_episode[eoff + c] : a.noise[(size_t)(t - a.noise_t0) * NP + c];
-                p.cap = a.cap[eoff + c];
-                p.sw = (c == a.seed_idx && a.qval_seed) ? a.sumw_seed[ti] : a.sumw[c];
-                if (a.ell_pos) p.pos = a.ell_pos[c];
+                p.k.beta0 = ld8(kb0, o8);
+                p.k.gamma = ld8(kcst, o8 + CST_GAMMA * np8);
+                p.k.ifr0 = ld8(kcst, o8 + CST_IFR0 * np8);
+                p.k.cnoise = ld8(kcst, o8 + CST_CNOISE * np8);
+                p.k.eff1 = ld8(kcst, o8 + CST_EFF1 * np8);
+                p.k.eff2 = ld8(kcst, o8 + CST_EFF2 * np8);
+                p.k.eff3 = ld8(kcst, o8 + CST_EFF3 * np8);
+                p.k.surge = ld8(kcst, o8 + CST_SURGE * np8);
+                p.k.vax6 = ld8(kcst, o8 + CST_VAX6 * np8);
+                p.k.vax7 = ld8(kcst, o8 + CST_VAX7 * np8);
+                p.act = ka->act_episode ? (int)ka->act_episode[eoff + c] : (int)ka->actions[(size_t)(t - ka->act_t0) * NP + c];
+                p.z = ka->noise_episode ? ld8(ka->noise_episode + eoff, o8) : ld8(ka->noise + (size_t)(t - ka->noise_t0) * NP, o8);
+                p.cap = ld8(kcap, o8);
+                p.sw = ((int)c == ka->seed_idx && ka->qval_seed) ? ka->sumw_seed[ti] : ld8(ka->sumw, o8);
+                if (ka->ell_pos) p.pos = ld4(ka->ell_pos, o4);
             }
             return p;
         };
         PatchIn nx = fetch(tid < n ? tid : 0);
         for (int cc = tid; cc < n; cc += kCsrThreads) {
-            int c = cc;
+            uint32_t c = (uint32_t)cc;
             asm volatile("" : "+v"(c));
+            const uint32_t o4 = c * 4u, o8 = c * 8u;
             PatchIn p = nx;
             nx = fetch(cc + kCsrThreads < n ? cc + kCsrThreads : cc);
             // every constant is fetched with the state, in one batch: left alone, the loads of those that only
@@ -769,12 +797,12 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 const int32_t movedI = (int32_t)(p.mi - (uint32_t)p.ei);
                 const double ns = fmax(0.0, (double)s0 + (double)movedS);
                 const double ni = fmax(0.0, (double)i0 + (double)movedI);
-                if (ns > 2147483647.0 || ni > 2147483647.0) record_error(sh_err, EPI_ERR_INT_RANGE, c, tc);
+                if (ns > 2147483647.0 || ni > 2147483647.0) record_error(sh_err, EPI_ERR_INT_RANGE, (int)c, tc);
                 s0 = (int32_t)ns;
                 i0 = (int32_t)ni;
                 tc = min(tc + 1, a.step_t_max);
-                if (p.arr < 0 && i0 >= 10) a.arrival[eoff + c] = t - 1;
-                if (i0 > p.pk) a.peak[eoff + c] = i0;
+                if (p.arr < 0 && i0 >= 10) st4(karr, o4, t - 1);
+                if (i0 > p.pk) st4(kpk, o4, i0);
                 if (a.flow_s) {
                     a.flow_s[eoff + c] = movedS;
                     a.flow_i[eoff + c] = movedI;
@@ -789,16 +817,17 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 const long long tb = (long long)s0 + i0 + r0 + d0 + v0;
                 const LocalOut o = local_step(p.k, s0, i0, r0, d0, v0, p.cap, act, p.z);
                 const long long ta = (long long)o.s + o.i + o.r + o.d + o.v;
-                if (a.validate && ta != tb) record_error(sh_err, EPI_ERR_LOCAL_MASS, c, tc);
-                if ((o.s | o.i | o.r | o.d | o.v) < 0) record_error(sh_err, EPI_ERR_INT_RANGE, c, tc);
+                if (a.validate && ta != tb) record_error(sh_err, EPI_ERR_LOCAL_MASS, (int)c, tc);
+                if ((o.s | o.i | o.r | o.d | o.v) < 0) record_error(sh_err, EPI_ERR_INT_RANGE, (int)c, tc);
                 if (a.rwd) a.reward_out[eoff + c] = reward_of(a.rwd[c], (double)i0, (double)d0, o, act);
-                st_s[c] = o.s; st_i[c] = o.i; st_r[c] = o.r; st_d[c] = o.d; st_v[c] = o.v;
-                a.cap[eoff + c] = o.cap;
+                st4(kst, o4, o.s); st4(kst, o4 + planeB, o.i); st4(kst, o4 + 2u * planeB, o.r); st4(kst, o4 + 3u * planeB, o.d);
+                st4(kst, o4 + 4u * planeB, o.v);
+                st8(kcap, o8, o.cap);
                 if (a.loc_s) { a.loc_s[eoff + c] = o.s; a.loc_i[eoff + c] = o.i; }
-                a.tcur[eoff + c] = tc + 1;
+                st4(ktc, o4, tc + 1);
                 const int32_t eS = export_count(max(0, o.s), p.sw), eI = export_count(max(0, o.i), p.sw);
-                expS[c] = eS;
-                expI[c] = eI;
+                st4(kex, o4, eS);
+                st4(kex, o4 + planeB, eI);
                 if (p.pos >= 0) {  // second copy where the mobility phase reads it with coalesced loads
                     expPS[p.pos] = eS;
                     expPI[p.pos] = eI;
@@ -806,9 +835,9 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 sh_mov[c] = 0ull;
                 mass_local += ta > 0 ? (unsigned long long)ta : 0ull;
             } else {
-                st_s[c] = s0;
-                st_i[c] = i0;
-                a.tcur[eoff + c] = tc;
+                st4(kst, o4, s0);
+                st4(kst, o4 + planeB, i0);
+                st4(ktc, o4, tc);
             }
         }
         if (a.validate) {
@@ -1121,6 +1150,7 @@ hipError_t launch_episode(const EpisodeArgs& a, hipStream_t s) {
     if (a.count <= 0 || a.t_end <= a.t_begin) return hipSuccess;
     if (a.rowptr) {
         if (csr_lds_bytes(a.n) > kMaxLdsBytes) return hipErrorInvalidValue;
+        if ((unsigned long long)a.count * a.npad * 5ull * sizeof(int32_t) > 0xffffffffull) return hipErrorInvalidValue;  // 32-bit plane offsets
         if (a.max_deg <= 16) return launch_csr<16>(a, s);
         if (a.max_deg <= 24) return launch_csr<24>(a, s);
         if (a.max_deg <= kLaneSlots) return launch_csr<kLaneSlots>(a, s);
