@@ -126,6 +126,30 @@ def test_mlp_greedy_matches_oracle(epi):
         assert act[k] == int(np.argmax(want))
 
 
+@pytest.mark.parametrize("hidden", [64, 128])
+def test_mlp_large_batches_equal_small_ones(epi, hidden):
+    """Batches of 128 states and more on one network of 64 or 128 hidden units take the tiled network kernel, smaller
+    ones the unit-per-thread kernel: same Q-values and actions, bit for bit, a ragged last tile included; for the
+    reference's width also against the oracle."""
+    rng = np.random.default_rng(17 + hidden)
+    W = epi.mlp_init(hidden)
+    states = []
+    for _ in range(333):
+        pop = int(rng.integers(1000, 10**9))
+        i = int(rng.integers(0, pop // 3)); r = int(rng.integers(0, pop // 3))
+        states.append(epi.State(pop - i - r, i, r, int(rng.integers(0, 1000)), int(rng.integers(0, 1000)),
+                                float(rng.choice([1.0, 1e4, 3e5])), int(rng.integers(0, 300)), 300, 1))
+    q, act = epi.mlp_greedy(states, W, 10.0)
+    for lo in range(0, len(states), 100):
+        qs, acts = epi.mlp_greedy(states[lo:lo + 100], W, 10.0)
+        np.testing.assert_array_equal(q[lo:lo + 100], qs)
+        np.testing.assert_array_equal(act[lo:lo + 100], acts)
+    assert np.abs(q).max() > 0
+    if hidden == 128:
+        for k in range(0, len(states), 7):
+            np.testing.assert_array_equal(q[k], O.mlp_predict(np.array(states[k].features()), 10.0))
+
+
 def test_unit_ops_keep_their_staging(epi):
     """The per-call entry points reuse device staging between calls (growing, shrinking and growing sizes again) and
     the cached network of epi_mlp_greedy_batch is replaced when any weight changes."""
@@ -810,6 +834,32 @@ def test_int_range_is_reported(epi):
         util.engine_grid(wl, synth.base_state(8))
     assert ei.value.status in (3, 4, 6)
     assert util.oracle_grid(wl, synth.base_state(8))["err"] != 0
+
+
+def test_int_range_in_a_sparse_sweep_names_the_callers_patch(epi):
+    """A sweep numbers the patches of a sparse graph in its own order inside the engine; a failure is reported under
+    the caller's patch number.  Patches 1500 and 1700 of a 2,000-patch ring pour 0.2 of two billion people each into
+    patch 1600: the first failure any episode meets is there (or at one of the two sources)."""
+    from epidemicsimulator_amd import synth
+    n = 2000
+    countries, xy = synth.make_countries(n, 5)
+    rows = [[((i + 1) % n, 0.01), ((i + 7) % n, 0.01)] for i in range(n)]
+    for src in (1500, 1700):
+        countries[src].pop = 2_000_000_000
+        rows[src] = [(1600, 0.2)]
+    countries[1600].pop = 100_000_000
+    rows = [sorted(r) for r in rows]
+    rp = np.zeros(n + 1, dtype=np.int32); rp[1:] = np.cumsum([len(r) for r in rows])
+    col = np.array([c for r in rows for c, _ in r], dtype=np.int32)
+    val = np.array([v for r in rows for _, v in r], dtype=np.float64)
+    wl = synth.small_workload(8, 1, 1, 6, seed=1)
+    wl["countries"], wl["profiles"], wl["conn"] = countries, countries, (rp, col, val)
+    wl["t_arrive"], wl["t_peak"] = synth.targets(n, 6, 1)
+    wl["seed_idx"] = 3
+    with pytest.raises(epi.EpiError) as ei:
+        util.engine_grid(wl, synth.base_state(6))
+    assert ei.value.status in (3, 4, 6)
+    assert any("country %d," % c in ei.value.message for c in (1500, 1600, 1700)), ei.value.message
 
 
 def test_bad_inputs_are_rejected(epi):
