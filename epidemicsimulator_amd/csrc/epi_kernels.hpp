@@ -50,7 +50,8 @@ struct EpisodeArgs {
     int n_ell;                // rows held in the blocks; with ell_rows == ell_pos == NULL row 64*b + l IS patch 64*b + l (patches numbered
                               // in lane-layout order, long rows last): no second copy of the exports, no scattered stores
     int seed_block;           // block that holds the seed row, -1 if it is a long row (or there are no variants)
-    const int32_t* col;       // ELL columns, ascending inside a row, -1 = padding; every block occupies a whole
+    const int32_t* col;       // ELL columns (patch ids in the numbering the kernel runs in; slots in the caller's ascending
+                              // column order, which is the order ties are broken in), -1 = padding; every block occupies a whole
                               // number of slot groups (kSlotGroup), the extra slots holding weight 0
     const double* qval;       // ELL normalised weights w_ij / sumW_i (a stored diagonal entry holds 0)
     const double* qval_seed;  // per travel scale: a copy [seed_deg][64] of the seed row's block with that row replaced,
