@@ -565,6 +565,7 @@ __device__ __forceinline__ void apportion_row_hist(int32_t E, int n, int diag, c
     constexpr int NB = 64 * R;
     const double Ed = (double)E;
     uint32_t key[R];
+    double fr[R];   // the fractions themselves: their bucket is floor(fraction * NB), which only the high word decides
     uint32_t bsum = 0;
     {
         double q[R];
@@ -574,7 +575,8 @@ __device__ __forceinline__ void apportion_row_hist(int32_t E, int n, int diag, c
         for (int r = 0; r < R; ++r) {
             const double raw = q[r] * Ed;
             const uint32_t b = (uint32_t)(int32_t)raw;  // raw >= 0: truncation is floor
-            key[r] = (uint32_t)__double2hiint(frac_of(raw));
+            fr[r] = frac_of(raw);
+            key[r] = (uint32_t)__double2hiint(fr[r]);
             acc[r] += b;
             bsum += b;
         }
@@ -594,7 +596,7 @@ __device__ __forceinline__ void apportion_row_hist(int32_t E, int n, int diag, c
     // padding columns (weight 0, fraction 0) stay out: dozens of lanes adding to one word would queue up behind each other
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        if (r * 64 + lane < n) atomicAdd(&hist[(uint32_t)(from_hi_word(key[r]) * (double)NB)], 1u);
+        if (r * 64 + lane < n) atomicAdd(&hist[(uint32_t)(fr[r] * (double)NB)], 1u);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     uint32_t c[R];
 #pragma unroll
