@@ -82,7 +82,7 @@ class WorldDesc(C.Structure):
 # Every symbol include/epi.h declares; tests check that the library exports all of them.
 EXPORTED_SYMBOLS = [
     "epi_version", "epi_last_error", "epi_last_status", "epi_device_count", "epi_set_device", "epi_alloc_int", "epi_alloc_int_batch",
-    "epi_env_step_batch", "epi_scale_row", "epi_gravity_matrix", "epi_gravity_csr", "epi_java_gaussians", "epi_agent_actions", "epi_mlp_init",
+    "epi_env_step_batch", "epi_scale_row", "epi_gravity_matrix", "epi_gravity_csr", "epi_java_gaussians", "epi_java_gaussian_table", "epi_agent_actions", "epi_mlp_init",
     "epi_mlp_greedy_batch", "epi_grid_create", "epi_grid_run", "epi_grid_run_strided", "epi_grid_run_noalloc", "epi_grid_status", "epi_grid_destroy",
     "epi_grid_argmin", "epi_calibrate_grid", "epi_grid_multi_create", "epi_grid_multi_run", "epi_grid_multi_ranks",
     "epi_grid_multi_destroy", "epi_calibrate_grid_multi", "epi_grid_set_timing", "epi_grid_kernel_time", "epi_world_create", "epi_world_step", "epi_world_step_greedy", "epi_world_rollout_greedy", "epi_world_keep_transitions",

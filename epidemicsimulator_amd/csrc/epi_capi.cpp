@@ -599,6 +599,19 @@ EPI_API int32_t epi_java_gaussians(int64_t seed, int32_t n, double* out) {
     return EPI_OK;
 }
 
+EPI_API int32_t epi_java_gaussian_table(int64_t seed0, int32_t streams, int32_t draws, double* out, int32_t device) {
+    if (streams < 0 || draws < 0 || ((size_t)streams * draws > 0 && !out))
+        return fail(EPI_ERR_BAD_ARGUMENT, "epi_java_gaussian_table: bad arguments");
+    if ((size_t)streams * draws == 0) return EPI_OK;
+    int32_t rc = use_device(device);
+    if (rc) return rc;
+    DevBuf tab;
+    HIP_TRY(tab.ensure(sizeof(double) * (size_t)streams * draws));
+    HIP_TRY(launch_gaussian_table(tab.as<double>(), nullptr, streams, draws, (size_t)streams, seed0, nullptr));
+    HIP_TRY(hipMemcpy(out, tab.p, sizeof(double) * (size_t)streams * draws, hipMemcpyDeviceToHost));
+    return EPI_OK;
+}
+
 EPI_API int32_t epi_agent_actions(const epi_hyper* hp, int32_t steps, int32_t* out) {
     if (!hp || steps < 0 || (steps > 0 && !out)) return fail(EPI_ERR_BAD_ARGUMENT, "epi_agent_actions: bad arguments");
     AgentStream ag;
@@ -915,20 +928,21 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
     // every rollout builds fresh envs and agents, so these are the same for all grid points.
     {
         const int T = d->steps > 0 ? d->steps : 1;
-        std::vector<double> hz((size_t)T * npad, 0.0);
         if (d->heterogeneous) {
-            for (int c = 0; c < n; ++c) {
-                JavaRandom r(c + 42);  // Calibrate.scala:36
-                for (int t = 0; t < d->steps; ++t) hz[(size_t)t * npad + in(c)] = r.nextGaussian();
-            }
+            // one stream per country, seeded idx + 42 (Calibrate.scala:36): drawn on the device, a thread per stream
+            HIP_TRY(G->noise.ensure(sizeof(double) * (size_t)T * npad));
+            HIP_TRY(hipMemsetAsync(G->noise.p, 0, sizeof(double) * (size_t)T * npad, nullptr));
+            HIP_TRY(launch_gaussian_table(G->noise.as<double>(), G->graph.renumbered ? G->graph.d_id_of.as<int32_t>() : nullptr, n,
+                                          d->steps, (size_t)npad, 42, nullptr));
         } else {
+            std::vector<double> hz((size_t)T * npad, 0.0);
             JavaRandom r(7);  // Calibrate.scala:32: every env is seeded 7
             for (int t = 0; t < d->steps; ++t) {
                 const double z = r.nextGaussian();
                 for (int c = 0; c < n; ++c) hz[(size_t)t * npad + c] = z;
             }
+            HIP_TRY(G->noise.upload(hz));
         }
-        HIP_TRY(G->noise.upload(hz));
         std::vector<int8_t> ha((size_t)T * npad, 0);
         AgentStream ag;  // all agents share seed 9 and the hyper-parameters: one stream serves all
         G->greedy_steps.clear();

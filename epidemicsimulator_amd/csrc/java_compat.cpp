@@ -13,8 +13,8 @@ constexpr uint64_t kMul = 0x5DEECE66DULL;
 constexpr uint64_t kAdd = 0xBULL;
 constexpr uint64_t kMask = (1ULL << 48) - 1;
 
-inline uint64_t bits_of(double x) { uint64_t b; std::memcpy(&b, &x, 8); return b; }
-inline double from_bits(uint64_t b) { double x; std::memcpy(&x, &b, 8); return x; }
+__host__ __device__ inline uint64_t bits_of(double x) { uint64_t b; __builtin_memcpy(&b, &x, 8); return b; }
+__host__ __device__ inline double from_bits(uint64_t b) { double x; __builtin_memcpy(&x, &b, 8); return x; }
 }  // namespace
 
 void JavaRandom::reseed(int64_t seed) {
@@ -61,7 +61,7 @@ double JavaRandom::nextGaussian() {
     return v1 * mul;
 }
 
-double strict_log(double x) {
+__host__ __device__ double strict_log(double x) {
     // Constants of the fdlibm natural logarithm: ln2 split in two parts, and the
     // minimax coefficients of (log(1+f) - 2s)/s in s^2, s = f/(2+f).
     constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
@@ -74,8 +74,8 @@ double strict_log(double x) {
     const uint32_t lx = static_cast<uint32_t>(b);
     int32_t k = 0;
     if (hx < 0x00100000) {  // zero, negative or subnormal
-        if (((hx & 0x7fffffff) | lx) == 0) return -std::numeric_limits<double>::infinity();
-        if (hx < 0) return std::numeric_limits<double>::quiet_NaN();
+        if (((hx & 0x7fffffff) | lx) == 0) return -__builtin_huge_val();
+        if (hx < 0) return __builtin_nan("");
         k -= 54;
         x *= two54;
         b = bits_of(x);
@@ -114,6 +114,63 @@ double strict_log(double x) {
     }
     if (k == 0) return f - s * (f - R);
     return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+// ---- the same generator on the device: one stream per thread ------------------------------------------------------
+namespace {
+struct DeviceRandom {
+    uint64_t state;
+    bool have_cached;
+    double cached;
+    __device__ void reseed(int64_t seed) {
+        state = (static_cast<uint64_t>(seed) ^ kMul) & kMask;
+        have_cached = false;
+        cached = 0.0;
+    }
+    __device__ int32_t next(int bits) {
+        state = (state * kMul + kAdd) & kMask;
+        return static_cast<int32_t>(static_cast<uint32_t>(state >> (48 - bits)));
+    }
+    __device__ double nextDouble() {
+        const int64_t a = next(26);
+        const int64_t b = next(27);
+        return static_cast<double>((a << 27) + b) * 0x1.0p-53;
+    }
+    __device__ double nextGaussian() {
+        if (have_cached) {
+            have_cached = false;
+            return cached;
+        }
+        double v1, v2, s;
+        do {
+            v1 = 2 * nextDouble() - 1;
+            v2 = 2 * nextDouble() - 1;
+            s = v1 * v1 + v2 * v2;
+        } while (s >= 1 || s == 0);
+        const double mul = sqrt(-2 * strict_log(s) / s);   // IEEE square root and division on both sides
+        cached = v2 * mul;
+        have_cached = true;
+        return v1 * mul;
+    }
+};
+
+__global__ void __launch_bounds__(64) gaussian_table_kernel(double* out, const int32_t* slot_of, int streams, int draws,
+                                                            size_t ld, int64_t seed0) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= streams) return;
+    DeviceRandom r;
+    r.reseed(seed0 + c);
+    double* col = out + (slot_of ? slot_of[c] : c);
+    for (int t = 0; t < draws; ++t) col[(size_t)t * ld] = r.nextGaussian();
+}
+}  // namespace
+
+hipError_t launch_gaussian_table(double* out, const int32_t* slot_of, int streams, int draws, size_t ld, int64_t seed0,
+                                 hipStream_t stream) {
+    if (streams <= 0 || draws <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gaussian_table_kernel, dim3((unsigned)((streams + 63) / 64)), dim3(64), 0, stream, out, slot_of, streams,
+                       draws, ld, seed0);
+    return hipGetLastError();
 }
 
 int AgentStream::act(const Hyper& hp) {

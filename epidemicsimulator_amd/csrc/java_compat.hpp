@@ -7,6 +7,9 @@
 // generator (48-bit LCG, nextDouble, nextInt(bound), polar nextGaussian on
 // StrictMath.log/sqrt) and the agent's action schedule.
 #pragma once
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#endif
 #include <cstdint>
 #include <vector>
 
@@ -30,7 +33,20 @@ private:
 
 // StrictMath.log (fdlibm e_log algorithm); differs from glibc log in the last ulp
 // for some arguments, which would change nextGaussian and hence trajectories.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
 double strict_log(double x);
+
+#if defined(__HIPCC__)
+// out[t * ld + slot_of[c]] (slot_of == NULL: column c) = the t-th nextGaussian() of a java.util.Random seeded
+// seed0 + c, for c < streams and t < draws, generated on the device: one thread per stream, the same operations in
+// the same order as JavaRandom::nextGaussian (every one of them rounds once on either side).  The per-country
+// environment noise of a heterogeneous sweep (Calibrate.scala:36: seed = idx + 42) is 4 million draws at 20,000
+// patches and 200 steps -- 60 ms of host time, most of the engine's creation.
+hipError_t launch_gaussian_table(double* out, const int32_t* slot_of, int streams, int draws, size_t ld, int64_t seed0,
+                                 hipStream_t stream);
+#endif
 
 // Fields of HyperParams the path reads (config.scala:3-21).
 struct Hyper {

@@ -121,6 +121,11 @@ int32_t epi_gravity_csr(int32_t n, const int32_t *pop, const double *lat, const 
 /* ---- JVM-compatible streams (scala.util.Random at env.scala:42,91; DDQNAgent.scala:14-32;
  *      MLP.scala:5-9) ------------------------------------------------------------------------- */
 int32_t epi_java_gaussians(int64_t seed, int32_t n, double *out);
+/* out[t * streams + c] = the t-th nextGaussian() of a java.util.Random seeded seed0 + c (t < draws, c < streams),
+ * generated on the device, a thread per stream: the per-country noise streams of a heterogeneous calibration
+ * (Calibrate.scala:36 seeds country idx with idx + 42; env.scala:91 draws one value per step).  Bit-identical to
+ * epi_java_gaussians(seed0 + c, draws, .) stream by stream. */
+int32_t epi_java_gaussian_table(int64_t seed0, int32_t streams, int32_t draws, double *out, int32_t device);
 /* Action stream of a fresh DDQNAgent for `steps` act() calls: 0..7, or -1 where it takes argmax Q. */
 int32_t epi_agent_actions(const epi_hyper *hp, int32_t steps, int32_t *out);
 /* Untrained network weights: W1[h*in], W2[h*h], W3[out*h]. */

@@ -106,6 +106,31 @@ def test_heterogeneity_spec(epi):
     assert a.i != b.i
 
 
+def test_gaussian_streams_on_the_device_equal_the_host_ones(epi):
+    """The per-country noise streams of a heterogeneous sweep are drawn on the device, a thread per stream (polar
+    method on StrictMath.log / sqrt): every draw equals the host generator's, which the oracle's own generator and
+    the JDK's documented algorithm pin."""
+    import ctypes as C
+    streams, draws = 1500, 257
+    tab = np.zeros((draws, streams))
+    epi.check(epi.lib().epi_java_gaussian_table(C.c_int64(42), C.c_int32(streams), C.c_int32(draws),
+                                                tab.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(0)))
+    one = np.zeros(draws)
+    for c in list(range(0, streams, 7)) + [streams - 1]:
+        epi.check(epi.lib().epi_java_gaussians(C.c_int64(42 + c), C.c_int32(draws), one.ctypes.data_as(C.POINTER(C.c_double))))
+        np.testing.assert_array_equal(tab[:, c], one)
+    assert abs(tab.mean()) < 0.01 and abs(tab.std() - 1.0) < 0.01
+    # negative and large seeds take the same path
+    for seed0 in (-5, 2**40 + 3):
+        t2 = np.zeros((9, 3))
+        epi.check(epi.lib().epi_java_gaussian_table(C.c_int64(seed0), C.c_int32(3), C.c_int32(9),
+                                                    t2.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(0)))
+        for c in range(3):
+            o = np.zeros(9)
+            epi.check(epi.lib().epi_java_gaussians(C.c_int64(seed0 + c), C.c_int32(9), o.ctypes.data_as(C.POINTER(C.c_double))))
+            np.testing.assert_array_equal(t2[:, c], o)
+
+
 # ---------------------------------------------------------------- MLP.predict / actGreedy
 def test_mlp_greedy_matches_oracle(epi):
     rng = np.random.default_rng(5)
