@@ -1223,7 +1223,7 @@ hipError_t launch_init(const InitArgs& a, hipStream_t s) {
 // Loss of one grid point (Calibrate.scala:14-17,103-109): the two root-mean-squares are summed
 // over countries in order by one lane so that every rounding matches the sequential reference.
 // ---------------------------------------------------------------------------------------------
-constexpr int kLossThreads = 256;
+constexpr int kLossThreads = 1024;
 constexpr int kLossChunk = 1024;   // countries whose squared errors are staged in LDS at a time
 
 // One workgroup per episode.  The squared errors are formed by all threads, a chunk of countries at a time; the two
@@ -1260,6 +1260,13 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(const LossArgs a) {
             const double* q = tid == 0 ? sh_qa : sh_qp;
             int k = 0;
             if (c0 == 0) { sum = q[0]; k = 1; }
+            for (; k + 16 <= m; k += 16) {   // sixteen LDS reads in flight, then the additions in order
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = q[k + u];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) sum = sum + v[u];
+            }
             for (; k < m; ++k) sum = sum + q[k];
         }
         __syncthreads();
