@@ -1441,6 +1441,176 @@ __global__ __launch_bounds__(256) void mlp_greedy_kernel(const MlpArgs a) {
     }
 }
 
+// The same evaluation for at most eight states per network (one world's greedy step, an evaluation rollout): one
+// workgroup of 1,024 threads per one or two states, and everything arranged for latency, because a lone workgroup has nothing
+// to overlap a memory round trip with.  Every weight the workgroup needs is requested in one go at the start:
+// thread (part, u) holds W2(u)(k) for the KPER inputs k of its part, the first Hp threads the first layer, thread
+// (o, k) one weight of the third.  The sums keep their order: the second layer's run over k = 0, 1, ... as a relay
+// through the parts (part s adds its KPER products to what part s - 1 left in LDS), the third layer's products are
+// formed by all threads at once and added in order by one thread per (state, output).
+// HP = hidden units = row stride of the network image (64 or 128: 16 parts of 4 inputs, 8 parts of 16).
+constexpr int MLP_CHAIN_THREADS = 1024;
+
+template <int HP, int ROWS>
+__global__ __launch_bounds__(MLP_CHAIN_THREADS) void mlp_chain_kernel(const MlpArgs a) {
+    constexpr int PARTS = MLP_CHAIN_THREADS / HP;
+    constexpr int KPER = HP / PARTS;
+    static_assert(PARTS * KPER == HP, "the parts cover the inputs");
+    __shared__ double sh_x[ROWS][8];
+    __shared__ double sh_h[ROWS][HP];        // first layer's activations, later the second layer's
+    __shared__ double sh_acc[ROWS][HP];      // the relay: partial sums of the second layer
+    __shared__ double sh_p3[ROWS][8][HP];    // products of the third layer
+    __shared__ double sh_y[ROWS][8];
+    const int tid = threadIdx.x;
+    const int part = tid / HP, u = tid % HP;
+    const int cfix = a.per_country ? (int)blockIdx.y : 0;
+    const double* __restrict__ net = a.nets + (a.per_country ? (size_t)cfix * a.net_stride : 0);
+    const NetLayout nl{HP, HP};
+    auto locate = [&](int r, int& e, int& c) {
+        if (a.per_country) {
+            e = blockIdx.x * ROWS + r;
+            c = cfix;
+            return e < a.count;
+        }
+        const int row = blockIdx.x * ROWS + r;
+        e = row / a.n;
+        c = row - e * a.n;
+        return row < a.rows;
+    };
+    // every weight this thread will use, requested before anything else
+    double w2[KPER];
+#pragma unroll
+    for (int j = 0; j < KPER; ++j) w2[j] = net[nl.w2t() + (size_t)(part * KPER + j) * HP + u];
+    double w1[7] = {0, 0, 0, 0, 0, 0, 0}, b1 = 0.0;
+    if (part == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) w1[k] = net[nl.w1t() + (size_t)k * HP + u];
+        b1 = net[nl.b1() + u];
+    }
+    const double b2 = part == PARTS - 1 ? net[nl.b2() + u] : 0.0;
+    // third layer: thread (o, k) for tid < 8 * HP
+    const int o3 = tid / HP, k3 = tid % HP;
+    const double w3 = o3 < 8 ? net[nl.w3() + (size_t)o3 * HP + k3] : 0.0;
+    const double b3 = tid < ROWS * 8 ? net[nl.b3() + (tid & 7)] : 0.0;
+    const double clip = a.clip_ptr ? a.clip_ptr[(size_t)cfix * a.clip_stride] : a.clip_q;
+
+    if (tid < ROWS) {
+        double f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int e, c;
+        if (locate(tid, e, c)) {
+            double s, i, r, d, v, cap;
+            int32_t t, tmax;
+            if (a.st) {
+                const size_t idx = (size_t)e * a.npad + c;
+                s = (double)a.st[0 * a.plane + idx]; i = (double)a.st[1 * a.plane + idx];
+                r = (double)a.st[2 * a.plane + idx]; d = (double)a.st[3 * a.plane + idx];
+                v = (double)a.st[4 * a.plane + idx];
+                cap = a.cap[idx]; t = a.tcur[idx]; tmax = a.state_t_max;
+            } else {
+                const epi_state& st = a.states[(size_t)e * a.n + c];
+                s = st.s; i = st.i; r = st.r; d = st.d; v = st.v; cap = st.hosp_cap; t = st.t; tmax = st.t_max;
+            }
+            const double N = fmax(1.0, s + i + r + d);
+            f[0] = s / N; f[1] = i / N; f[2] = r / N; f[3] = d / N; f[4] = v / N;
+            f[5] = i / fmax(1.0, cap);
+            f[6] = (double)t / (double)(tmax > 1 ? tmax : 1);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sh_x[tid][k] = f[k];
+    }
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            double acc = w1[0] * sh_x[r][0];
+#pragma unroll
+            for (int k = 1; k < 7; ++k) acc = acc + w1[k] * sh_x[r][k];
+            const double z = acc + b1;
+            sh_h[r][u] = z > 0 ? z : 0.0;
+        }
+    }
+    __syncthreads();
+    // second layer: the products of this thread's inputs (formed ahead of the relay while they fit the registers),
+    // then the relay
+    constexpr bool kAhead = ROWS * KPER <= 32;
+    double p[kAhead ? ROWS : 1][KPER];
+    if constexpr (kAhead) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int j = 0; j < KPER; ++j) p[r][j] = w2[j] * sh_h[r][part * KPER + j];
+    }
+#pragma unroll 1
+    for (int stage = 0; stage < PARTS; ++stage) {
+        if (part == stage) {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                if constexpr (!kAhead) {
+#pragma unroll
+                    for (int j = 0; j < KPER; ++j) p[0][j] = w2[j] * sh_h[r][part * KPER + j];
+                }
+                const double* pr = p[kAhead ? r : 0];
+                double acc = stage == 0 ? pr[0] : sh_acc[r][u] + pr[0];
+#pragma unroll
+                for (int j = 1; j < KPER; ++j) acc = acc + pr[j];
+                sh_acc[r][u] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    if (part == PARTS - 1) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const double z = sh_acc[r][u] + b2;
+            sh_h[r][u] = z > 0 ? z : 0.0;   // every product of the first layer's activations has been formed
+        }
+    }
+    __syncthreads();
+    if (o3 < 8) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) sh_p3[r][o3][k3] = w3 * sh_h[r][k3];
+    }
+    __syncthreads();
+    if (tid < ROWS * 8) {
+        const int r = tid >> 3, o = tid & 7;
+        const double* q = sh_p3[r][o];
+        double y = q[0];
+        for (int k = 1; k + 16 <= HP; k += 16) {   // sixteen LDS reads in flight, then the additions in order
+            double v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = q[k + j];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) y = y + v[j];
+        }
+#pragma unroll
+        for (int k = HP - 15; k < HP; ++k) y = y + q[k];
+        y = y + b3;
+        if (isfinite(clip)) y = fmax(-clip, fmin(clip, y));
+        sh_y[r][o] = y;
+    }
+    __syncthreads();
+    if (tid < ROWS) {
+        int e, c;
+        if (locate(tid, e, c)) {
+            const size_t row = (size_t)e * a.n + c;
+            int best = 0;
+            for (int o = 1; o < 8; ++o)
+                if (sh_y[tid][o] > sh_y[tid][best]) best = o;
+            if (a.act_episode) a.act_episode[(size_t)e * a.npad + c] = (int8_t)best;
+            if (a.act_out) a.act_out[row] = best;
+            if (a.q_out)
+                for (int o = 0; o < 8; ++o) a.q_out[row * 8 + o] = sh_y[tid][o];
+        }
+    }
+}
+
+template <int HP, int ROWS>
+static hipError_t launch_mlp_chain(const MlpArgs& a, int live, hipStream_t s) {
+    const dim3 grid((unsigned)((live + ROWS - 1) / ROWS), a.per_country ? (unsigned)a.n : 1u);
+    hipLaunchKernelGGL((mlp_chain_kernel<HP, ROWS>), grid, dim3(MLP_CHAIN_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
 // The same evaluation for large batches that share a network (the argmax-Q step of a sweep: every patch of every
 // episode).  A workgroup of two waves evaluates 32 states as four tiles of 8: thread (w, g, q) -- wave w, g = lane / 16,
 // q = lane % 16 -- owns the UN = HP / 32 hidden units (16 w + q) * UN .. + UN - 1 for the 8 states of tile g.  Per input k
@@ -1649,6 +1819,12 @@ hipError_t launch_mlp(const MlpArgs& a, hipStream_t s) {
         if (H == 64) hipLaunchKernelGGL(mlp_tile_kernel<64>, grid, dim3(MLP_TILE_THREADS), 0, s, a);
         else hipLaunchKernelGGL(mlp_tile_kernel<128>, grid, dim3(MLP_TILE_THREADS), 0, s, a);
         return hipGetLastError();
+    }
+    if (live <= 8 && H == a.nl.Hp && (H == 64 || H == 128)) {
+        // a handful of states per network: the latency-first kernel, two states per workgroup (the workgroups of one
+        // launch run side by side on different CUs, and two states' products still fit the registers)
+        if (H == 64) return live <= 1 ? launch_mlp_chain<64, 1>(a, live, s) : launch_mlp_chain<64, 2>(a, live, s);
+        return live <= 1 ? launch_mlp_chain<128, 1>(a, live, s) : launch_mlp_chain<128, 2>(a, live, s);
     }
     if (live <= 1) return launch_mlp_rows<1>(a, live, s);
     if (live <= 2) return launch_mlp_rows<2>(a, live, s);

@@ -170,6 +170,11 @@ def test_mlp_large_batches_equal_small_ones(epi, hidden):
         np.testing.assert_array_equal(q[lo:lo + 100], qs)
         np.testing.assert_array_equal(act[lo:lo + 100], acts)
     assert np.abs(q).max() > 0
+    # one to eight states take the latency-first kernel (weights requested at once, sums relayed through the parts)
+    for cnt, lo in ((1, 0), (1, 77), (2, 10), (3, 20), (4, 30), (5, 40), (7, 50), (8, 60)):
+        qs, acts = epi.mlp_greedy(states[lo:lo + cnt], W, 10.0)
+        np.testing.assert_array_equal(q[lo:lo + cnt], qs)
+        np.testing.assert_array_equal(act[lo:lo + cnt], acts)
     if hidden == 128:
         for k in range(0, len(states), 7):
             np.testing.assert_array_equal(q[k], O.mlp_predict(np.array(states[k].features()), 10.0))
