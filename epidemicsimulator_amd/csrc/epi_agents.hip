@@ -506,7 +506,7 @@ struct epi_agents {
     std::vector<Replay> replay;
     std::vector<double> ema;
     DevBuf nets, hyper, H1, H2, Q, DZ2, DZ1, ERR, X0d, ACTd, ring, ring_off;
-    PinBuf slot_agent, slot_rows, X, idx, loss, push_rec, push_dst, file_dst;
+    PinBuf slot_agent, slot_rows, X, idx, loss, push_rec, push_dst, file_dst, q_in, q_out, q_act;
     std::vector<long long> h_ring_off;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -774,35 +774,29 @@ EPI_API int32_t epi_agents_q_values(epi_agents* g, const int32_t* ids, int32_t c
     if (int32_t rc = check_ids(g, ids, count)) return rc;
     if (count == 0) return EPI_OK;
     if (int32_t rc = use_device(g->device)) return rc;
-    const int Bp = g->Bp;
-    for (int k = 0; k < count; ++k) {
-        g->slot_agent.as<int32_t>()[k] = ids ? ids[k] : k;
-        g->slot_rows.as<int32_t>()[k] = 1;
-        double* X0 = g->X.as<double>() + (size_t)k * kXStride;
-        features(s[k], X0); X0[7] = 0.0;
-    }
-    AgentsArgs a = g->args();
-    a.n_classes = 1;
-    a.idx = nullptr;  // one directly staged row per slot
-    a.net_of_class[0] = use_target ? 1 : 0; a.x_of_class[0] = 0;
-    // class 0 also writes the hidden activations of row 0 of each slot: scratch no later call relies on
-    hipLaunchKernelGGL(agents_forward_kernel<16>, dim3(1, count), dim3(g->nl.Hp / 16 * 64), tile_lds_bytes(), g->stream, a, a.nets);
-    HIP_TRY(hipGetLastError());
-    std::vector<double> out((size_t)count * kOut);
-    for (int k = 0; k < count; ++k)
-        HIP_TRY(hipMemcpyAsync(out.data() + (size_t)k * kOut, g->Q.as<double>() + ((size_t)k * 3) * Bp * kOut, kOut * 8,
-                               hipMemcpyDeviceToHost, g->stream));
+    // DDQNAgent.actGreedy / MLP.predict (DDQNAgent.scala:22-23, MLP.scala:15-22), one state per asked agent: the
+    // network kernels of the world step, each state with its agent's online (or target) network; states, Q-values
+    // and actions pass through page-locked memory the kernel reads and writes itself.
+    HIP_TRY(g->q_in.ensure((size_t)count * sizeof(epi_state)));
+    HIP_TRY(g->q_out.ensure((size_t)count * kOut * sizeof(double)));
+    HIP_TRY(g->q_act.ensure((size_t)count * sizeof(int32_t)));
+    std::memcpy(g->q_in.p, s, (size_t)count * sizeof(epi_state));
+    for (int k = 0; k < count; ++k) g->slot_agent.as<int32_t>()[k] = ids ? ids[k] : k;
+    MlpArgs ma{};
+    ma.rows = count; ma.n = count; ma.npad = count; ma.count = 1;
+    ma.states = g->q_in.on_device<epi_state>();
+    ma.nl = g->nl; ma.nets = g->nets.as<double>(); ma.net_stride = 2 * g->nl.size();
+    ma.net_offset = use_target ? g->nl.size() : 0;
+    ma.net_index = g->slot_agent.on_device<int32_t>();
+    ma.per_country = 1;
+    ma.clip_ptr = reinterpret_cast<const double*>(g->hyper.as<AgentHyperDev>()) + 2;   // AgentHyperDev::clip_q
+    ma.clip_stride = (int)(sizeof(AgentHyperDev) / sizeof(double));
+    ma.q_out = g->q_out.on_device<double>();
+    ma.act_out = g->q_act.on_device<int32_t>();
+    HIP_TRY(launch_mlp(ma, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
-    for (int k = 0; k < count; ++k) {
-        const double* y = out.data() + (size_t)k * kOut;
-        if (q) std::copy(y, y + kOut, q + (size_t)k * kOut);
-        if (greedy) {
-            int best = 0;
-            for (int o = 1; o < kOut; ++o)
-                if (y[o] > y[best]) best = o;
-            greedy[k] = best;
-        }
-    }
+    if (q) std::memcpy(q, g->q_out.p, (size_t)count * kOut * sizeof(double));
+    if (greedy) std::memcpy(greedy, g->q_act.p, (size_t)count * sizeof(int32_t));
     return EPI_OK;
 }
 

@@ -1313,7 +1313,8 @@ __global__ __launch_bounds__(256) void mlp_greedy_kernel(const MlpArgs a) {
     double* sh_h2 = sh_h1 + ROWS * H;        // [ROWS][H]
     const int tid = threadIdx.x;
     const int cfix = a.per_country ? (int)blockIdx.y : 0;
-    const double* __restrict__ net = a.nets + (a.per_country ? (size_t)cfix * a.net_stride : 0);
+    const size_t nidx = a.per_country ? (size_t)(a.net_index ? a.net_index[cfix] : cfix) : 0;
+    const double* __restrict__ net = a.nets + nidx * a.net_stride + a.net_offset;
     // row r of this workgroup -> (episode, country); false past the end
     auto locate = [&](int r, int& e, int& c) {
         if (a.per_country) {
@@ -1421,7 +1422,7 @@ __global__ __launch_bounds__(256) void mlp_greedy_kernel(const MlpArgs a) {
             }
         }
         double y = acc + net[a.nl.b3() + o];
-        const double clip = a.clip_ptr ? a.clip_ptr[(size_t)cfix * a.clip_stride] : a.clip_q;
+        const double clip = a.clip_ptr ? a.clip_ptr[nidx * a.clip_stride] : a.clip_q;
         if (isfinite(clip)) y = fmax(-clip, fmin(clip, y));
         sh_y[r * 8 + o] = y;
     }
@@ -1464,7 +1465,8 @@ __global__ __launch_bounds__(MLP_CHAIN_THREADS) void mlp_chain_kernel(const MlpA
     const int tid = threadIdx.x;
     const int part = tid / HP, u = tid % HP;
     const int cfix = a.per_country ? (int)blockIdx.y : 0;
-    const double* __restrict__ net = a.nets + (a.per_country ? (size_t)cfix * a.net_stride : 0);
+    const size_t nidx = a.per_country ? (size_t)(a.net_index ? a.net_index[cfix] : cfix) : 0;
+    const double* __restrict__ net = a.nets + nidx * a.net_stride + a.net_offset;
     const NetLayout nl{HP, HP};
     auto locate = [&](int r, int& e, int& c) {
         if (a.per_country) {
@@ -1492,7 +1494,7 @@ __global__ __launch_bounds__(MLP_CHAIN_THREADS) void mlp_chain_kernel(const MlpA
     const int o3 = tid / HP, k3 = tid % HP;
     const double w3 = o3 < 8 ? net[nl.w3() + (size_t)o3 * HP + k3] : 0.0;
     const double b3 = tid < ROWS * 8 ? net[nl.b3() + (tid & 7)] : 0.0;
-    const double clip = a.clip_ptr ? a.clip_ptr[(size_t)cfix * a.clip_stride] : a.clip_q;
+    const double clip = a.clip_ptr ? a.clip_ptr[nidx * a.clip_stride] : a.clip_q;
 
     if (tid < ROWS) {
         double f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1634,7 +1636,8 @@ __global__ __launch_bounds__(MLP_TILE_THREADS) void mlp_tile_kernel(const MlpArg
     const int lane = tid & 63;
     const int g = lane >> 4;
     const int cfix = a.per_country ? (int)blockIdx.y : 0;
-    const double* __restrict__ net = a.nets + (a.per_country ? (size_t)cfix * a.net_stride : 0);
+    const size_t nidx = a.per_country ? (size_t)(a.net_index ? a.net_index[cfix] : cfix) : 0;
+    const double* __restrict__ net = a.nets + nidx * a.net_stride + a.net_offset;
     const NetLayout nl{HP, HP};
     auto locate = [&](int r, int& e, int& c) {
         if (a.per_country) {
@@ -1771,7 +1774,7 @@ __global__ __launch_bounds__(MLP_TILE_THREADS) void mlp_tile_kernel(const MlpArg
         batch3(0, std::true_type{});
 #pragma nounroll
         for (int k0 = 8; k0 < HP; k0 += 8) batch3(k0, std::false_type{});
-        const double clip = a.clip_ptr ? a.clip_ptr[(size_t)cfix * a.clip_stride] : a.clip_q;
+        const double clip = a.clip_ptr ? a.clip_ptr[nidx * a.clip_stride] : a.clip_q;
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
             double v = y[o] + net[nl.b3() + o0 + o];

@@ -166,6 +166,8 @@ struct MlpArgs {
     NetLayout nl;
     const double* nets;       // network(s) in NetLayout form
     size_t net_stride;        // doubles from country c's network to country c+1's (per_country)
+    const int32_t* net_index; // optional (per_country): country c asks network net_index[c] instead of network c
+    size_t net_offset;        // doubles added to every network's address (the target network of an agent's pair)
     int per_country;
     double clip_q;            // clamp of the outputs (MLP.scala:21), used when clip_ptr == NULL
     const double* clip_ptr;   // per-country clamp: clip_ptr[c * clip_stride]
