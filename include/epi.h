@@ -172,7 +172,9 @@ epi_grid *epi_grid_create(const epi_grid_desc *desc);
  * reference's loop order).  loss[g_count]; arrival[g_count][n] and peak[g_count][n] may be NULL.
  * With out_on_device != 0 the three pointers are device memory on the handle's device, the work is
  * only enqueued on `stream` (a hipStream_t, NULL = default stream) and the status of the run is
- * collected by epi_grid_status().  Otherwise they are host memory and the call is synchronous. */
+ * collected by epi_grid_status().  Otherwise they are host memory and the call is synchronous.
+ * A sparse world (more than 1,024 countries) takes at most 2^32 / (20 * npad) grid points per call, npad = n rounded up
+ * to 64 (10,720 at 20,000 patches): larger calls return EPI_ERR_UNSUPPORTED and are split by the caller. */
 int32_t epi_grid_run(epi_grid *g, int32_t g_begin, int32_t g_count, double *loss, int32_t *arrival, double *peak,
                      int32_t out_on_device, void *stream);
 /* The same for the grid points g_begin + k * g_stride, k < g_count (outputs indexed by k).  An interleaved split
