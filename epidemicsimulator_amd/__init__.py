@@ -715,6 +715,15 @@ class WorldToy:
         rw = np.ctypeslib.as_array(C.cast(pr, C.POINTER(C.c_double)), shape=(cells,))
         return st.view(WorldToy.STATE_DTYPE).reshape(self.batch, self.n), rw.reshape(self.batch, self.n)
 
+    def packed_array(self):
+        """numpy view of the handle's page-locked array of 32-byte state records (PACKED_DTYPE [batch][n]); passed as
+        out_states to step_arrays_packed it is filled by the device without a further copy."""
+        ps = C.c_void_p()
+        check(lib().epi_world_packed_buffer(self._h, C.byref(ps)))
+        cells = self.batch * self.n
+        st = np.ctypeslib.as_array(C.cast(ps, C.POINTER(C.c_uint8)), shape=(cells * WorldToy.PACKED_DTYPE.itemsize,))
+        return st.view(WorldToy.PACKED_DTYPE).reshape(self.batch, self.n)
+
     def __del__(self):
         try:
             self.close()
@@ -796,6 +805,26 @@ class WorldToy:
         check(lib().epi_world_step(self._h, ptr(a, C.c_int32), ptr(g, C.c_double) if g is not None else None,
                                    C.c_int32(self.base.t_max if t_max is None else t_max),
                                    C.cast(out_states.ctypes.data, C.POINTER(_capi.CState)), ptr(out_rewards, C.c_double)))
+        return out_states, out_rewards
+
+    # the states of step_arrays in half the bytes: whole-number compartments as int32, t_max and seed left out (they
+    # are the base state's for every instance)
+    PACKED_DTYPE = np.dtype([("s", "i4"), ("i", "i4"), ("r", "i4"), ("d", "i4"), ("v", "i4"), ("t", "i4"),
+                             ("hosp_cap", "f8")])
+
+    def step_arrays_packed(self, actions, gauss=None, t_max: Optional[int] = None, out_states=None, out_rewards=None):
+        """step_arrays with the states as PACKED_DTYPE records (32 bytes instead of 64 per instance and country)."""
+        a = i32(np.asarray(actions).reshape(self.batch, self.n))
+        g = None if gauss is None else f64(np.asarray(gauss).reshape(self.batch, self.n))
+        if out_states is None:
+            out_states = np.empty((self.batch, self.n), dtype=WorldToy.PACKED_DTYPE)
+        if out_rewards is None:
+            out_rewards = np.empty((self.batch, self.n))
+        assert out_states.dtype == WorldToy.PACKED_DTYPE and out_states.flags.c_contiguous
+        assert out_rewards.dtype == np.float64 and out_rewards.flags.c_contiguous
+        check(lib().epi_world_step_packed(self._h, ptr(a, C.c_int32), ptr(g, C.c_double) if g is not None else None,
+                                          C.c_int32(self.base.t_max if t_max is None else t_max),
+                                          C.c_void_p(out_states.ctypes.data), ptr(out_rewards, C.c_double)))
         return out_states, out_rewards
 
     def set_timing(self, on: bool):

@@ -87,7 +87,7 @@ EXPORTED_SYMBOLS = [
     "epi_grid_argmin", "epi_calibrate_grid", "epi_grid_multi_create", "epi_grid_multi_run", "epi_grid_multi_ranks",
     "epi_grid_multi_destroy", "epi_calibrate_grid_multi", "epi_grid_set_timing", "epi_grid_kernel_time", "epi_world_create", "epi_world_step", "epi_world_step_greedy", "epi_world_rollout_greedy", "epi_world_keep_transitions",
     "epi_world_set_mlp", "epi_world_get_states", "epi_world_set_states", "epi_world_reset", "epi_world_last_flows",
-    "epi_world_set_timing", "epi_world_kernel_time", "epi_world_result_buffers", "epi_world_destroy",
+    "epi_world_set_timing", "epi_world_kernel_time", "epi_world_result_buffers", "epi_world_step_packed", "epi_world_packed_buffer", "epi_world_destroy",
     "epi_agents_create", "epi_agents_destroy", "epi_agents_observe", "epi_agents_observe_world", "epi_agents_replay_size", "epi_agents_sample",
     "epi_agents_learn", "epi_agents_q_values", "epi_agents_get_weights", "epi_agents_set_weights",
     "epi_agents_set_timing", "epi_agents_kernel_time",
@@ -129,6 +129,8 @@ def lib():
         L.epi_grid_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.epi_world_result_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                                C.POINTER(C.c_void_p)]
+        L.epi_world_step_packed.argtypes = [C.c_void_p, _PI, _PD, C.c_int32, C.c_void_p, _PD]
+        L.epi_world_packed_buffer.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.epi_world_rollout_greedy.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p]
         L.epi_world_set_timing.argtypes = [C.c_void_p, C.c_int32]

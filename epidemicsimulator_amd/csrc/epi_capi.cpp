@@ -551,7 +551,7 @@ struct epi_world {
     bool keep_tr = false, have_tr = false;
     DevBuf prev_st, prev_cap, prev_tcur, loc_s, loc_i;
     // compact [batch][n] images of the caller's arrays in page-locked, device-mapped host memory
-    PinBuf pin_act, pin_gauss, pin_states, pin_rewards, pin_actions, pin_err;
+    PinBuf pin_act, pin_gauss, pin_states, pin_packed, pin_rewards, pin_actions, pin_err;
 
     std::vector<JavaRandom> env_rnd;  // one stream per country (env.scala:42)
     std::vector<int32_t> env_seeds;
@@ -1408,6 +1408,7 @@ static int32_t world_build(epi_world* Wd, const epi_world_desc* d) {
     HIP_TRY(Wd->pin_act.ensure(compact * sizeof(int32_t)));
     HIP_TRY(Wd->pin_gauss.ensure(compact * sizeof(double)));
     HIP_TRY(Wd->pin_states.ensure(compact * sizeof(epi_state)));
+    HIP_TRY(Wd->pin_packed.ensure(compact * sizeof(epi_state_packed)));
     HIP_TRY(Wd->pin_rewards.ensure(compact * sizeof(double)));
     HIP_TRY(Wd->pin_actions.ensure(compact * sizeof(int32_t)));
     HIP_TRY(Wd->pin_err.ensure((size_t)d->batch * 4 * sizeof(int32_t)));
@@ -1517,7 +1518,8 @@ EPI_API int32_t epi_world_set_mlp(epi_world* w, int32_t hidden, const double* W1
 }
 
 static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy, const double* gauss, int32_t t_max,
-                               epi_state* out_states, double* out_rewards, int32_t* out_actions) {
+                               epi_state* out_states, double* out_rewards, int32_t* out_actions,
+                               epi_state_packed* out_packed = nullptr) {
     const int n = w->n, npad = w->npad, B = w->batch;
     const size_t cells = (size_t)B * npad, compact = (size_t)B * n;
     HIP_TRY(hipSetDevice(w->device));
@@ -1583,6 +1585,7 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
     if (fused) {
         ea.io_actions = io.actions; ea.io_gauss = io.gauss; ea.io_gauss_row = io.gauss_row;
         ea.io_states = out_states ? w->pin_states.on_device<epi_state>() : nullptr;
+        ea.io_packed = out_packed ? w->pin_packed.on_device<epi_state_packed>() : nullptr;
         ea.io_rewards = out_rewards ? w->pin_rewards.on_device<double>() : nullptr;
         ea.io_err = w->pin_err.on_device<int32_t>();
         ea.io_t_max = w->base.t_max; ea.io_seed = w->base.seed;
@@ -1594,6 +1597,7 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
     // Results: the unpack kernel writes compact records straight into the handle's page-locked, device-mapped
     // result arrays; a caller that reads them in place (epi_world_result_buffers) gets no further copy.
     if (out_states) io.states_out = w->pin_states.on_device<epi_state>();
+    if (out_packed) io.packed_out = w->pin_packed.on_device<epi_state_packed>();
     if (out_rewards) io.rewards_out = w->pin_rewards.on_device<double>();
     if (out_actions) io.actions_out = w->pin_actions.on_device<int32_t>();
     io.err_out = w->pin_err.on_device<int32_t>();
@@ -1609,6 +1613,7 @@ static int32_t world_step_impl(epi_world* w, const int32_t* actions, bool greedy
     w->have_flows = true;
     w->have_tr = w->keep_tr;
     if (out_states && out_states != w->pin_states.p) std::memcpy(out_states, w->pin_states.p, compact * sizeof(epi_state));
+    if (out_packed && out_packed != w->pin_packed.p) std::memcpy(out_packed, w->pin_packed.p, compact * sizeof(epi_state_packed));
     if (out_rewards && out_rewards != w->pin_rewards.p) std::memcpy(out_rewards, w->pin_rewards.p, compact * sizeof(double));
     if (out_actions && out_actions != w->pin_actions.p) std::memcpy(out_actions, w->pin_actions.p, compact * sizeof(int32_t));
     const int32_t* he = w->pin_err.as<int32_t>();
@@ -1623,6 +1628,18 @@ EPI_API int32_t epi_world_step(epi_world* w, const int32_t* actions, const doubl
                                epi_state* out_states, double* out_rewards) {
     if (!w || !actions) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_step: null argument");
     return world_step_impl(w, actions, false, gauss, t_max, out_states, out_rewards, nullptr);
+}
+
+EPI_API int32_t epi_world_step_packed(epi_world* w, const int32_t* actions, const double* gauss, int32_t t_max,
+                                      epi_state_packed* out_states, double* out_rewards) {
+    if (!w || !actions) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_step_packed: null argument");
+    return world_step_impl(w, actions, false, gauss, t_max, nullptr, out_rewards, nullptr, out_states);
+}
+
+EPI_API int32_t epi_world_packed_buffer(epi_world* w, epi_state_packed** states) {
+    if (!w || !states) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_packed_buffer: null argument");
+    *states = w->pin_packed.as<epi_state_packed>();
+    return EPI_OK;
 }
 
 EPI_API int32_t epi_world_step_greedy(epi_world* w, const double* gauss, int32_t t_max, epi_state* out_states,

@@ -1117,6 +1117,12 @@ __global__ __launch_bounds__(64) void episode_tiny_kernel(const EpisodeArgs a) {
         out.t = tcur; out.t_max = a.io_t_max; out.seed = a.io_seed; out.pad_ = 0;
         a.io_states[(size_t)e * n + c] = out;
     }
+    if (real && a.io_packed) {
+        epi_state_packed out;
+        out.s = s; out.i = i; out.r = r; out.d = d; out.v = v; out.t = tcur;
+        out.hosp_cap = cap;
+        a.io_packed[(size_t)e * n + c] = out;
+    }
     if (real) {
         a.st[0 * plane + eoff + c] = s;
         a.st[1 * plane + eoff + c] = i;
@@ -1963,6 +1969,17 @@ __global__ void world_unpack_kernel(const WorldIoArgs a) {
             s.hosp_cap = a.cap[o];
             s.t = a.tcur[o];
             a.states_out[k] = s;
+        }
+        if (a.packed_out) {
+            epi_state_packed s;
+            s.s = a.st[0 * plane + o];
+            s.i = a.st[1 * plane + o];
+            s.r = a.st[2 * plane + o];
+            s.d = a.st[3 * plane + o];
+            s.v = a.st[4 * plane + o];
+            s.t = a.tcur[o];
+            s.hosp_cap = a.cap[o];
+            a.packed_out[k] = s;
         }
         if (a.rewards_out) a.rewards_out[k] = a.reward_pad[o];
         if (a.actions_out) a.actions_out[k] = (int32_t)a.act_pad[o];

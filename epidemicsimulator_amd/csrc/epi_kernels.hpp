@@ -94,6 +94,7 @@ struct EpisodeArgs {
     const double* io_gauss;      // [count][n] noise draws, or NULL: io_gauss_row[n], one draw per country for all instances
     const double* io_gauss_row;
     epi_state* io_states;        // [count][n] State records out (t_max and seed from io_t_max / io_seed), or NULL
+    epi_state_packed* io_packed; // [count][n] the same states as 32-byte records, or NULL
     double* io_rewards;          // [count][n] or NULL
     int32_t* io_err;             // [count][4] copy of the error table
     int32_t io_t_max, io_seed;
@@ -202,6 +203,7 @@ struct WorldIoArgs {
     const int32_t* st; const double* cap; const int32_t* tcur; const double* reward_pad;
     epi_state base;           // t_max, seed copied into every state
     epi_state* states_out;    // [batch][n]
+    epi_state_packed* packed_out;   // [batch][n] the same states as 32-byte records
     double* rewards_out;      // [batch][n]
     int32_t* actions_out;     // [batch][n]
     int32_t* err_out;         // [batch][4] copy of the error table (optional)

@@ -267,6 +267,19 @@ int32_t epi_world_step(epi_world *w, const int32_t *actions, const double *gauss
  * of epi_world_step / epi_world_step_greedy reads the results in place, without the copy into caller memory.
  * They belong to the handle and are overwritten by the next step. */
 int32_t epi_world_result_buffers(epi_world *w, epi_state **states, double **rewards, int32_t **actions);
+/* Optional (no counterpart in the reference): epi_world_step with the states returned as 32-byte records instead
+ * of 64-byte ones, for callers that read every instance's results every step over PCIe (a batched rollout of small
+ * worlds is bound by exactly that transfer).  Nothing is lost: the compartments of every state the step produces
+ * are whole numbers below 2^31 (env.scala:81-85, 244-262), and t_max and seed are those of the base state.
+ * epi_world_packed_buffer returns the handle's page-locked array of such records; passed as out_states it is read in
+ * place, like the arrays of epi_world_result_buffers (whose rewards array serves out_rewards here too). */
+typedef struct epi_state_packed {
+    int32_t s, i, r, d, v, t;
+    double hosp_cap;
+} epi_state_packed;
+int32_t epi_world_step_packed(epi_world *w, const int32_t *actions, const double *gauss, int32_t t_max,
+                              epi_state_packed *out_states, double *out_rewards);
+int32_t epi_world_packed_buffer(epi_world *w, epi_state_packed **states);
 /* WorldToy.stepOneGreedy (:172-235): actions = argmax Q(features) with the weights set below. */
 int32_t epi_world_step_greedy(epi_world *w, const double *gauss, int32_t t_max, epi_state *out_states,
                               double *out_rewards, int32_t *out_actions);

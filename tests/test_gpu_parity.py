@@ -289,6 +289,42 @@ def test_world_result_arrays_equal_copied(epi):
     wa.close(); wb.close()
 
 
+@pytest.mark.parametrize("kind", ["toy", "dense30", "sparse900"])
+def test_world_packed_states_equal_the_full_records(epi, kind):
+    """epi_world_step_packed: the 32-byte state records hold the same numbers as the 64-byte ones of epi_world_step,
+    field by field and step by step, read in place or copied -- on the toy world (the kernel writes the records
+    itself), on a dense world and on a sparse one (the unpack kernel writes them)."""
+    from epidemicsimulator_amd import synth
+    if kind == "toy":
+        countries, conn, B = list(epi.ToyConn.C), epi.ToyConn.W, 37
+    elif kind == "dense30":
+        countries, xy = synth.make_countries(30, 8)
+        conn, B = synth.gravity_dense(countries, xy), 5
+    else:
+        countries, xy = synth.make_countries(900, 21)
+        conn, B = synth.gravity_csr(countries, xy, mean_degree=9.0), 3
+    n = len(countries)
+    wa, _, rng = _world_pair(epi, countries, conn, batch=B)
+    wb, _, _ = _world_pair(epi, countries, conn, batch=B)
+    pk = wb.packed_array()
+    _, rw_b = wb.result_arrays()
+    assert pk.shape == (B, n) and pk.dtype.itemsize == 32
+    for step in range(6):
+        acts = rng.integers(0, 8, (B, n)); gauss = rng.normal(size=(B, n))
+        st_a, rw_a = wa.step_arrays(acts, gauss, 120)
+        if step == 2:
+            got_s, got_r = wb.step_arrays_packed(acts, gauss, 120)
+        else:
+            got_s, got_r = wb.step_arrays_packed(acts, gauss, 120, pk, rw_b)
+            assert got_s is pk
+        for f in ("s", "i", "r", "d", "v", "t", "hosp_cap"):
+            np.testing.assert_array_equal(got_s[f], st_a[f], err_msg=f)
+        np.testing.assert_array_equal(got_r, rw_a)
+    assert int(st_a["i"].sum()) > 0
+    del pk, rw_b, got_s, got_r
+    wa.close(); wb.close()
+
+
 def test_world_step_one_and_greedy_follow_reference_streams(epi):
     """stepOne / stepOneGreedy with the JVM-compatible agent and env streams (EvalDeterminismSpec.scala
     inputs: base tMax=120, beta 0.26, noise 0.02), checked against the oracle's WorldToy."""
