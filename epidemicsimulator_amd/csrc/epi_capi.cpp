@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -809,6 +810,16 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
     if (rc) return rc;
     rc = use_device(d->device);
     if (rc) return rc;
+    // EPI_CREATE_TIMERS=1: wall time of every stage of the build on stderr (diagnostic)
+    const bool timers = getenv("EPI_CREATE_TIMERS") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+        if (!timers) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[epi create] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     G->device = d->device;
     G->n = d->n; G->steps = d->steps; G->n_beta = d->n_beta; G->n_travel = d->n_travel; G->seed_idx = d->seed_idx;
     G->base = d->base;
@@ -816,6 +827,7 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
     // filed under in(c), and the loss kernel reads arrival / peak back through the same map
     rc = G->graph.build(d->n, d->pop, d->conn, d->csr_rowptr, d->csr_col, d->csr_val, true);
     if (rc) return rc;
+    stamp("graph tables");
     const int n = d->n, npad = G->graph.npad;
     G->npad = npad;
     auto in = [&](int c) { return (size_t)G->graph.inner(c); };
@@ -886,6 +898,7 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
             HIP_TRY(hipDeviceSynchronize());   // d_travel goes out of scope
         }
     }
+    stamp("seed-row variants");
     G->graph.d_W.release();   // the tables are complete: the matrix itself is not read again
     G->graph.W.clear(); G->graph.W.shrink_to_fit();
     // per-country environments (Calibrate.scala:31-51)
@@ -924,6 +937,7 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
         HIP_TRY(G->beta0.upload(hb));
         HIP_TRY(G->cst.upload(hc));
     }
+    stamp("env constants");
     // noise draws z[t][c] (env.scala:91) and the shared action stream (DDQNAgent.scala:26-32):
     // every rollout builds fresh envs and agents, so these are the same for all grid points.
     {
@@ -963,6 +977,7 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
                             "rollouts that consult trained weights are not part of the sweep engine",
                             learn_from, hp.learn_every, hp.batch_size, gs);
     }
+    stamp("noise and actions");
     if (!G->greedy_steps.empty()) {
         std::vector<double> w1, w2, w3;
         mlp_init(7, hp.hidden, 8, w1, w2, w3);  // untrained online network (DDQNAgent.scala:8)
@@ -982,6 +997,7 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
         HIP_TRY(G->has_arrive.upload(ha));
         HIP_TRY(G->has_peak.upload(hk));
     }
+    stamp("network and targets");
     return EPI_OK;
 }
 

@@ -369,6 +369,23 @@ __device__ __noinline__ uint32_t tie_select(const double* __restrict__ qrow, dou
 // bisection every fourth probe as the safeguard that bounds the iteration count.
 // The search proper, from any valid bracket: #{key >= lo} = clo > rem > chi = #{key >= hi} (clo = n for lo = 0),
 // or `found` with the threshold in `mid`.  Adds the selected units to acc.
+// #{r : key[r] >= K} of this lane for keys and K below 2^30 (high words of fractions), 1 <= K.  key + (2^31 - K) has
+// its top bit set exactly when key >= K; a funnel shift collects the top bits of all slots in one register and one
+// population count adds them up.  Two plain integer instructions per key, like a compare and an add-with-carry, but
+// none of them writes or reads a condition register: those cost about 4.4 cycles per wave instruction against 3 for
+// an addition, and each pair needs two wait states between its halves.
+template <int R>
+__device__ __forceinline__ uint32_t count_ge(const uint32_t (&key)[R], uint32_t K) {
+    const uint32_t C = 0x80000000u - K;
+    uint32_t u0 = 0u, u1 = 0u;   // two chains, so that consecutive funnel shifts do not wait for each other
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (r & 1) u1 = __builtin_amdgcn_alignbit(u1, key[r] + C, 31);
+        else u0 = __builtin_amdgcn_alignbit(u0, key[r] + C, 31);
+    }
+    return (uint32_t)__popc(u0) + (uint32_t)__popc(u1);
+}
+
 template <int R>
 __device__ __forceinline__ void search_tail(const uint32_t (&key)[R], uint32_t (&acc)[R], double Ed, int32_t rem, int n,
                                             int diag, const double* __restrict__ qrow, int lane, Warm* warm, uint32_t hint,
@@ -383,19 +400,21 @@ __device__ __forceinline__ void search_tail(const uint32_t (&key)[R], uint32_t (
     constexpr int kSnap = (R <= 4) ? 2 : 1;  // measured best on the 200- and the 1,000-country grids
     while (!found && hi - lo > 1u) {
         if (lo_probed && clo - rem <= kSnap && !(hi_probed && rem - chi < clo - rem)) {
+            // key - lo wraps around to more than 2^31 for the keys below lo (all keys are below 2^30): one subtraction and
+            // one minimum per key, no compare / select pair
             uint32_t x = 0xffffffffu;
 #pragma unroll
-            for (int r = 0; r < R; ++r) x = min(x, key[r] >= lo ? key[r] : 0xffffffffu);
-            x = wave_min(x);          // lo <= x < hi, and no key lies in [lo, x)
-            lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+            for (int r = 0; r < R; ++r) x = min(x, key[r] - lo);
+            x = wave_min(x);          // lo <= lo + x < hi, and no key lies in [lo, lo + x)
+            lo += (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
             if (hi - lo <= 1u) break;  // every key of the bracket shares one high word: tie
             mid = lo + 1u;
         } else if (hi_probed && rem - chi <= kSnap) {
-            uint32_t y = 0u;
+            uint32_t y = 0xffffffffu;   // (hi - 1) - key wraps around for the keys at or above hi
 #pragma unroll
-            for (int r = 0; r < R; ++r) y = max(y, key[r] < hi ? key[r] : 0u);
-            y = wave_max(y);          // lo <= y < hi, and no key lies in (y, hi)
-            hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)y) + 1u;
+            for (int r = 0; r < R; ++r) y = min(y, (hi - 1u) - key[r]);
+            y = wave_min(y);          // hi - 1 - y is the largest key below hi: no key lies above it and below hi
+            hi -= (uint32_t)__builtin_amdgcn_readfirstlane((int)y);
             if (hi - lo <= 1u) break;
             mid = hi - 1u;
         } else if (it == 0 && hint != 0u) {
@@ -422,10 +441,7 @@ __device__ __forceinline__ void search_tail(const uint32_t (&key)[R], uint32_t (
         mid = max(mid, lo + 1u);
         mid = min(mid, hi - 1u);
         mid = (uint32_t)__builtin_amdgcn_readfirstlane((int)mid);
-        uint32_t cu = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) cu += (key[r] >= mid);
-        const int c = (int)wave_sum(cu);
+        const int c = (int)wave_sum(count_ge<R>(key, mid));
         if (last_c >= 0 && abs(c - last_c) >= 3 && mid != last_k) {
             const float s2 = (float)(from_hi_word(mid) - from_hi_word(last_k)) * __builtin_amdgcn_rcpf((float)(last_c - c));
             if (s2 > 0.f) slope = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s2)));
