@@ -173,9 +173,13 @@ def run_c5(args, rank, local_rank, world, use_dist):
     acts = rng.integers(0, 8, size=(64, B, n), dtype=np.int32)  # a ring of pre-drawn action batches
     states, rewards = w.result_arrays()   # the handle's page-locked result arrays, read in place by the trainer
     packed = args.c5_records == "packed"
+    resident = args.c5_records == "none"
     if packed:
         states = w.packed_array()
     step = w.step_arrays_packed if packed else w.step_arrays
+    if resident:
+        def step(a, g, t_max, _states, _rewards):
+            w.step_resident(a, g, t_max)
 
     def fence():
         if use_dist:
@@ -208,8 +212,11 @@ def run_c5(args, rank, local_rank, world, use_dist):
         "value": float(world) * B * n * args.steps / elapsed, "unit": "country-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(1, args.steps) * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "c5: %d instances of the %d-country toy world, one world step per iteration, actions in, "
-                               "states%s and rewards out over PCIe every step" % (B, n, " (32-byte records)" if packed else ""),
+        "config": {"workload": ("c5: %d instances of the %d-country toy world, one world step per iteration, actions in, "
+                                "states%s and rewards out over PCIe every step" % (B, n, " (32-byte records)" if packed else ""))
+                               if not resident else
+                               ("c5: %d instances of the %d-country toy world, one world step per iteration, actions in, states "
+                                "and rewards left on the device (NULL outputs)" % (B, n)),
                    "instances_per_gpu": B, "country_steps_per_step": world * B * n,
                    "parallelism": "independent replicas" if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -221,7 +228,7 @@ def run_c5(args, rank, local_rank, world, use_dist):
                      "note": "one launch per step of 4,096 six-country worlds; the kernel reads the actions from and writes "
                              "states and rewards to page-locked host memory itself, so avg_launch_ms is mostly the PCIe "
                              "transfer (%.1f MB per step) and the HBM roofline does not describe it"
-                             % (B * n * (52.0 if packed else 84.0) / 1e6)},
+                             % (B * n * (4.0 if resident else (52.0 if packed else 84.0)) / 1e6)},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
@@ -388,9 +395,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3")
-    ap.add_argument("--c5-records", choices=("full", "packed"), default="full",
-                    help="c5 only: states come back as 64-byte records (epi_world_step) or as 32-byte ones "
-                         "(epi_world_step_packed)")
+    ap.add_argument("--c5-records", choices=("full", "packed", "none"), default="full",
+                    help="c5 only: states come back as 64-byte records (epi_world_step), as 32-byte ones "
+                         "(epi_world_step_packed), or not at all (NULL outputs: the states stay on the device for "
+                         "device-side consumers, only the actions cross the bus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="threads of the cpu_baseline leg; 0 = the host cores this process may use")

@@ -807,6 +807,15 @@ class WorldToy:
                                    C.cast(out_states.ctypes.data, C.POINTER(_capi.CState)), ptr(out_rewards, C.c_double)))
         return out_states, out_rewards
 
+    def step_resident(self, actions, gauss=None, t_max: Optional[int] = None):
+        """step_arrays with nothing returned: epi_world_step with NULL out_states / out_rewards.  The states stay on
+        the device (read them with snapshot_states / epi_world_get_states, or let the learners file the transitions
+        with epi_agents_observe_world); only the actions -- and `gauss`, if given -- cross the bus."""
+        a = i32(np.asarray(actions).reshape(self.batch, self.n))
+        g = None if gauss is None else f64(np.asarray(gauss).reshape(self.batch, self.n))
+        check(lib().epi_world_step(self._h, ptr(a, C.c_int32), ptr(g, C.c_double) if g is not None else None,
+                                   C.c_int32(self.base.t_max if t_max is None else t_max), None, None))
+
     # the states of step_arrays in half the bytes: whole-number compartments as int32, t_max and seed left out (they
     # are the base state's for every instance)
     PACKED_DTYPE = np.dtype([("s", "i4"), ("i", "i4"), ("r", "i4"), ("d", "i4"), ("v", "i4"), ("t", "i4"),

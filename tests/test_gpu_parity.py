@@ -325,6 +325,41 @@ def test_world_packed_states_equal_the_full_records(epi, kind):
     wa.close(); wb.close()
 
 
+@pytest.mark.parametrize("kind", ["toy", "dense30", "csr900"])
+def test_world_step_without_outputs_leaves_the_same_states_on_the_device(epi, kind):
+    """epi_world_step with NULL out_states / out_rewards (WorldToy.step_resident): nothing comes back per step, and the
+    states the world holds afterwards (snapshotStates) and the flows of the last step are those of the same steps taken
+    with outputs -- on the toy world (the kernel writes no records), a dense world and a sparse one (no unpack)."""
+    from epidemicsimulator_amd import synth
+    if kind == "toy":
+        countries, conn, B = list(epi.ToyConn.C), epi.ToyConn.W, 37
+    elif kind == "dense30":
+        countries, xy = synth.make_countries(30, 8)
+        conn, B = synth.gravity_dense(countries, xy), 5
+    else:
+        countries, xy = synth.make_countries(900, 21)
+        conn, B = synth.gravity_csr(countries, xy, mean_degree=9.0), 3
+    n = len(countries)
+    wa, _, rng = _world_pair(epi, countries, conn, batch=B)
+    wb, _, _ = _world_pair(epi, countries, conn, batch=B)
+    for step in range(7):
+        acts = rng.integers(0, 8, (B, n)); gauss = rng.normal(size=(B, n))
+        st_a, _ = wa.step_arrays(acts, gauss, 120)
+        assert wb.step_resident(acts, gauss, 120) is None
+    snap_a, snap_b = wa.snapshot_states(), wb.snapshot_states()
+    if B == 1:
+        snap_a, snap_b = [snap_a], [snap_b]
+    for b in range(B):
+        for c in range(n):
+            assert snap_a[b][c] == snap_b[b][c], (b, c)
+            assert snap_b[b][c].i == st_a["i"][b, c]
+    fa, fb = wa.last_flows(), wb.last_flows()
+    np.testing.assert_array_equal(fa[0], fb[0])
+    np.testing.assert_array_equal(fa[1], fb[1])
+    assert int(st_a["i"].sum()) > 0
+    wa.close(); wb.close()
+
+
 def test_world_step_one_and_greedy_follow_reference_streams(epi):
     """stepOne / stepOneGreedy with the JVM-compatible agent and env streams (EvalDeterminismSpec.scala
     inputs: base tMax=120, beta 0.26, noise 0.02), checked against the oracle's WorldToy."""
