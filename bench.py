@@ -230,6 +230,14 @@ def run_c5(args, rank, local_rank, world, use_dist):
                              "transfer (%.1f MB per step) and the HBM roofline does not describe it"
                              % (B * n * (4.0 if resident else (52.0 if packed else 84.0)) / 1e6)},
     }
+    # the bus this workload is defined to cross: result bytes per step over the kernel time (the kernel writes them to
+    # page-locked host memory itself), against the raw rate of a PCIe 5.0 x16 link (32 GT/s x 16 lanes x 128/130)
+    out_bytes = B * n * (0.0 if resident else (32.0 + 8.0 if packed else 64.0 + 8.0)) + B * 16.0
+    out["roofline_pcie"] = {"bound": "pcie 5.0 x16, device to host", "achieved": out_bytes * k_launches / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
+                            "peak": 63.0, "unit": "GB/s", "result_bytes_per_step": out_bytes,
+                            "note": "kernel time includes a fixed 0.015 ms (the step with nothing returned, --c5-records none); "
+                                    "the returned bytes beyond that travel at about 56 GB/s (full vs packed vs none records)"}
+    out["roofline_pcie"]["frac"] = out["roofline_pcie"]["achieved"] / 63.0
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             c1 = synth.workload("c1")
