@@ -457,8 +457,30 @@ struct MlpDevice {
         std::vector<double> img(nl.size());
         pack_net(nl, w1, bb1, w2, bb2, w3, bb3, img.data());
         HIP_TRY(net.upload(img));
+        // constants of the screen pass's error bound (MlpArgs::cert): largest absolute row sum and bias per layer
+        auto norms = [](const double* w, const double* b, int rows, int cols, double& A, double& B) {
+            A = B = 0.0;
+            for (int r = 0; r < rows; ++r) {
+                double sum = 0.0;
+                for (int c = 0; c < cols; ++c) sum += std::fabs(w[(size_t)r * cols + c]);
+                A = std::fmax(A, sum);
+                if (b) B = std::fmax(B, std::fabs(b[r]));
+            }
+        };
+        norms(w1, bb1, h, 7, cert[0], cert[1]);
+        norms(w2, bb2, h, h, cert[2], cert[3]);
+        norms(w3, bb3, 8, h, cert[4], cert[5]);
+        bool finite = true;
+        for (double v : cert) finite = finite && std::isfinite(v);
+        // EPI_MLP_CERTIFY=0 switches the screen off; =all sends every state to the exact evaluation (tests)
+        const char* env = getenv("EPI_MLP_CERTIFY");
+        certify = finite && !(env && env[0] == '0');
+        cert_scale = (env && std::strcmp(env, "all") == 0) ? 1e300 : 1.0;
         return EPI_OK;
     }
+    int certify = 0;
+    double cert[6] = {0, 0, 0, 0, 0, 0};
+    double cert_scale = 1.0;
     void fill(MlpArgs& a) const {
         a.nl = nl;
         a.nets = net.as<double>();
@@ -467,6 +489,9 @@ struct MlpDevice {
         a.clip_q = clip_q;
         a.clip_ptr = nullptr;
         a.clip_stride = 0;
+        a.certify = certify;
+        for (int k = 0; k < 6; ++k) a.cert[k] = cert[k];
+        a.cert_scale = cert_scale;
     }
 };
 

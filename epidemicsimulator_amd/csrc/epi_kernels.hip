@@ -1630,11 +1630,32 @@ static hipError_t launch_mlp_chain(const MlpArgs& a, int live, hipStream_t s) {
 constexpr int MLP_TILE_ROWS = 32;
 constexpr int MLP_TILE_THREADS = 128;
 
-template <int HP>
+//
+// MODE 0: the evaluation as described.
+// MODE 1 (screen): the same sums with fused multiply-adds -- half the vector instructions of the second layer -- when
+//   only the greedy action is wanted.  The fused values are not the reference's, but both lie within e3 of the network
+//   evaluated in real arithmetic on the same features (the standard forward bound: a dot product of m terms plus a bias,
+//   in any order, fused or not, is off by at most gamma_(m+1) * (sum |w x| + |b|); ReLU and the clamp do not expand
+//   errors).  With A_k the largest absolute row sum of layer k's weights, B_k its largest absolute bias and X the
+//   largest absolute feature:  H1 = A1 X + B1,  e1 = g8 H1,  H2 = A2 H1 + B2,  e2 = A2 e1 + g (A2 (H1 + e1) + B2),
+//   e3 = A3 e2 + g (A3 (H2 + e2) + B3),  g = gamma_(HP+1).  Where the best fused value exceeds every other one by more
+//   than 4 e3 the reference's values differ strictly the same way and its first argmax is the fused one: that action is
+//   final.  Every other state (near ties, values at the clamp) is flagged (kActUncertain).
+// MODE 2: MODE 0 for the tiles that hold a flagged state, a return for all others.
+constexpr double kUnitRoundoff = 1.1102230246251565e-16;   // 2^-53
+
+template <bool FUSED>
+__device__ __forceinline__ double mac(double w, double x, double acc) {
+    if constexpr (FUSED) return __builtin_fma(w, x, acc);
+    else return acc + w * x;
+}
+
+template <int HP, int MODE>
 __global__ __launch_bounds__(MLP_TILE_THREADS) void mlp_tile_kernel(const MlpArgs a) {
     constexpr int UN = HP / 32;     // units per thread
     constexpr int TM = 8;           // states per tile
     constexpr int KB = 4;           // inputs whose weights are fetched together
+    constexpr bool FUSED = MODE == 1;
     __shared__ __align__(16) double sh_x[MLP_TILE_ROWS][8];
     __shared__ __align__(16) double sh_h[HP][MLP_TILE_ROWS];   // activations, input-major: [k][state]
     __shared__ __align__(16) double sh_y[MLP_TILE_ROWS][8];
@@ -1656,6 +1677,14 @@ __global__ __launch_bounds__(MLP_TILE_THREADS) void mlp_tile_kernel(const MlpArg
         c = row - e * a.n;
         return row < a.rows;
     };
+    if constexpr (MODE == 2) {
+        int flagged = 0;
+        if (tid < MLP_TILE_ROWS) {
+            int e, c;
+            if (locate(tid, e, c)) flagged = a.act_episode[(size_t)e * a.npad + c] & kActUncertain;
+        }
+        if (!__syncthreads_or(flagged)) return;
+    }
     if (tid < MLP_TILE_ROWS) {
         double f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int e, c;
@@ -1676,6 +1705,12 @@ __global__ __launch_bounds__(MLP_TILE_THREADS) void mlp_tile_kernel(const MlpArg
             f[0] = s / N; f[1] = i / N; f[2] = r / N; f[3] = d / N; f[4] = v / N;
             f[5] = i / fmax(1.0, cap);
             f[6] = (double)t / (double)(tmax > 1 ? tmax : 1);
+            if constexpr (MODE == 1) {   // slot 7 is not an input: it carries the largest absolute feature to the bound
+                double X = 0.0;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) X = fmax(X, fabs(f[k]));
+                f[7] = X;
+            }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) sh_x[tid][k] = f[k];
@@ -1706,7 +1741,7 @@ __global__ __launch_bounds__(MLP_TILE_THREADS) void mlp_tile_kernel(const MlpArg
             for (int u = 0; u < UN; ++u) {
                 double acc = w[0][u] * x[0];
 #pragma unroll
-                for (int k = 1; k < 7; ++k) acc = acc + w[k][u] * x[k];
+                for (int k = 1; k < 7; ++k) acc = mac<FUSED>(w[k][u], x[k], acc);
                 const double z = acc + b[u];
                 sh_h[u0 + u][g * TM + r] = z > 0 ? z : 0.0;
             }
@@ -1736,9 +1771,8 @@ __global__ __launch_bounds__(MLP_TILE_THREADS) void mlp_tile_kernel(const MlpArg
             for (int u = 0; u < UN; ++u)
 #pragma unroll
                 for (int r = 0; r < TM; ++r) {
-                    const double p = wc[j][u] * h[r];
-                    if (decltype(first)::value && j == 0) acc[u][r] = p;
-                    else acc[u][r] = acc[u][r] + p;
+                    if (decltype(first)::value && j == 0) acc[u][r] = wc[j][u] * h[r];
+                    else acc[u][r] = mac<FUSED>(wc[j][u], h[r], acc[u][r]);
                 }
         }
     };
@@ -1772,9 +1806,8 @@ __global__ __launch_bounds__(MLP_TILE_THREADS) void mlp_tile_kernel(const MlpArg
             for (int j = 0; j < 8; ++j)
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
-                    const double p = w[o][j] * h[j];
-                    if (decltype(first)::value && j == 0) y[o] = p;
-                    else y[o] = y[o] + p;
+                    if (decltype(first)::value && j == 0) y[o] = w[o][j] * h[j];
+                    else y[o] = mac<FUSED>(w[o][j], h[j], y[o]);
                 }
         };
         batch3(0, std::true_type{});
@@ -1796,10 +1829,24 @@ __global__ __launch_bounds__(MLP_TILE_THREADS) void mlp_tile_kernel(const MlpArg
             int best = 0;
             for (int o = 1; o < 8; ++o)
                 if (sh_y[tid][o] > sh_y[tid][best]) best = o;
-            if (a.act_episode) a.act_episode[(size_t)e * a.npad + c] = (int8_t)best;
-            if (a.act_out) a.act_out[row] = best;
-            if (a.q_out)
-                for (int o = 0; o < 8; ++o) a.q_out[row * 8 + o] = sh_y[tid][o];
+            if constexpr (MODE == 1) {
+                double second = -__builtin_inf();
+                for (int o = 0; o < 8; ++o)
+                    if (o != best) second = fmax(second, sh_y[tid][o]);
+                const double X = sh_x[tid][7];
+                const double g8 = 8.0 * 1.01 * kUnitRoundoff, gh = (double)(HP + 1) * 1.01 * kUnitRoundoff;
+                const double A1 = a.cert[0], B1 = a.cert[1], A2 = a.cert[2], B2 = a.cert[3], A3 = a.cert[4], B3 = a.cert[5];
+                const double H1 = A1 * X + B1, e1 = g8 * H1;
+                const double H2 = A2 * H1 + B2, e2 = A2 * e1 + gh * (A2 * (H1 + e1) + B2);
+                const double e3 = A3 * e2 + gh * (A3 * (H2 + e2) + B3);
+                const bool sure = (sh_y[tid][best] - second) > 4.0 * e3 * a.cert_scale;   // false for NaN as well
+                a.act_episode[(size_t)e * a.npad + c] = (int8_t)(sure ? best : (best | kActUncertain));
+            } else {
+                if (a.act_episode) a.act_episode[(size_t)e * a.npad + c] = (int8_t)best;
+                if (a.act_out) a.act_out[row] = best;
+                if (a.q_out)
+                    for (int o = 0; o < 8; ++o) a.q_out[row * 8 + o] = sh_y[tid][o];
+            }
         }
     }
 }
@@ -1825,8 +1872,19 @@ hipError_t launch_mlp(const MlpArgs& a, hipStream_t s) {
     const int live = a.per_country ? a.count : a.rows;   // states that share a network
     if (live >= 4 * MLP_TILE_ROWS && H == a.nl.Hp && (H == 64 || H == 128)) {   // a large batch on one network
         const dim3 grid((unsigned)((live + MLP_TILE_ROWS - 1) / MLP_TILE_ROWS), a.per_country ? (unsigned)a.n : 1u);
-        if (H == 64) hipLaunchKernelGGL(mlp_tile_kernel<64>, grid, dim3(MLP_TILE_THREADS), 0, s, a);
-        else hipLaunchKernelGGL(mlp_tile_kernel<128>, grid, dim3(MLP_TILE_THREADS), 0, s, a);
+        if (a.certify && a.act_episode && !a.act_out && !a.q_out && !a.per_country) {
+            // the action alone is wanted: fused screen, then the reference's arithmetic where the screen was not sure
+            if (H == 64) {
+                hipLaunchKernelGGL((mlp_tile_kernel<64, 1>), grid, dim3(MLP_TILE_THREADS), 0, s, a);
+                hipLaunchKernelGGL((mlp_tile_kernel<64, 2>), grid, dim3(MLP_TILE_THREADS), 0, s, a);
+            } else {
+                hipLaunchKernelGGL((mlp_tile_kernel<128, 1>), grid, dim3(MLP_TILE_THREADS), 0, s, a);
+                hipLaunchKernelGGL((mlp_tile_kernel<128, 2>), grid, dim3(MLP_TILE_THREADS), 0, s, a);
+            }
+            return hipGetLastError();
+        }
+        if (H == 64) hipLaunchKernelGGL((mlp_tile_kernel<64, 0>), grid, dim3(MLP_TILE_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((mlp_tile_kernel<128, 0>), grid, dim3(MLP_TILE_THREADS), 0, s, a);
         return hipGetLastError();
     }
     if (live <= 8 && H == a.nl.Hp && (H == 64 || H == 128)) {

@@ -176,7 +176,16 @@ struct MlpArgs {
     int8_t* act_episode;  // [count][npad] (when st != NULL)
     int32_t* act_out;     // [rows] optional
     double* q_out;        // [rows][8] optional
+    // Large batches that only want the greedy action (the argmax-Q step of a sweep): certify != 0 lets launch_mlp
+    // screen the states with fused multiply-adds first and evaluate in the reference's arithmetic only where the
+    // screen cannot certify the argmax (mlp_tile_kernel).  cert = {A1, B1, A2, B2, A3, B3}: the largest absolute row
+    // sum of each weight matrix and the largest absolute bias of each layer; cert_scale multiplies the error bound
+    // (1 in production; a huge value sends every state to the exact evaluation, for tests).
+    int certify;
+    double cert[6];
+    double cert_scale;
 };
+constexpr int8_t kActUncertain = 0x40;   // flag on an act_episode entry between the screen and the exact pass
 
 struct AllocBatchArgs {
     int n, npad, batch;
