@@ -1839,7 +1839,9 @@ __global__ __launch_bounds__(MLP_TILE_THREADS) void mlp_tile_kernel(const MlpArg
                 const double H1 = A1 * X + B1, e1 = g8 * H1;
                 const double H2 = A2 * H1 + B2, e2 = A2 * e1 + gh * (A2 * (H1 + e1) + B2);
                 const double e3 = A3 * e2 + gh * (A3 * (H2 + e2) + B3);
-                const bool sure = (sh_y[tid][best] - second) > 4.0 * e3 * a.cert_scale;   // false for NaN as well
+                // (the floor covers products that underflow, which the relative bound does not see: at most a few
+                // hundred roundings of 2^-1074 each; the comparison is false for NaN as well)
+                const bool sure = (sh_y[tid][best] - second) > 4.0 * e3 * a.cert_scale + 1e-300;
                 a.act_episode[(size_t)e * a.npad + c] = (int8_t)(sure ? best : (best | kActUncertain));
             } else {
                 if (a.act_episode) a.act_episode[(size_t)e * a.npad + c] = (int8_t)best;
