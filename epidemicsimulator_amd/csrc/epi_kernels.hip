@@ -1748,6 +1748,50 @@ __global__ __launch_bounds__(MLP_TILE_THREADS) void mlp_tile_kernel(const MlpArg
         }
     }
     __syncthreads();
+    if constexpr (MODE == 1) {
+        // Second layer of the screen on the matrix cores (v_mfma_f64_16x16x4_f64: D[16 units][16 states] += A[16 units][4 inputs]
+        // * B[4 inputs][16 states], one double of A and of B per lane -- A[lane & 15][lane >> 4], B[lane >> 4][lane & 15] -- and
+        // four of D: row (lane >> 4) + 4 r, column lane & 15).  Any summation order is as good as another to the screen's
+        // error bound.  A wave owns half of the HP / 16 unit tiles for both 16-state tiles of the workgroup: per four inputs
+        // it reads its weights once (W2 transposed: 16 consecutive units per input) and the activations once per state tile.
+        typedef double f64x4 __attribute__((ext_vector_type(4)));
+        constexpr int UT = HP / 32;   // unit tiles per wave
+        const int w = tid >> 6, lr = lane & 15, lq = lane >> 4;
+        const double* __restrict__ W2Tm = net + nl.w2t() + (size_t)lq * HP + (size_t)w * UT * 16 + lr;
+        f64x4 d[UT][2];
+#pragma unroll
+        for (int t = 0; t < UT; ++t) { d[t][0] = f64x4{0, 0, 0, 0}; d[t][1] = f64x4{0, 0, 0, 0}; }
+        double an[UT];
+#pragma unroll
+        for (int t = 0; t < UT; ++t) an[t] = W2Tm[t * 16];
+#pragma nounroll
+        for (int k0 = 0; k0 < HP; k0 += 4) {
+            double ac[UT];
+#pragma unroll
+            for (int t = 0; t < UT; ++t) ac[t] = an[t];
+            if (k0 + 4 < HP) {
+#pragma unroll
+                for (int t = 0; t < UT; ++t) an[t] = W2Tm[(size_t)(k0 + 4) * HP + t * 16];
+            }
+            const double b0 = sh_h[k0 + lq][lr], b1 = sh_h[k0 + lq][16 + lr];
+#pragma unroll
+            for (int t = 0; t < UT; ++t) {
+                d[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], b0, d[t][0], 0, 0, 0);
+                d[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], b1, d[t][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();   // every wave has read the first layer's activations: the buffer takes the second layer's
+#pragma unroll
+        for (int t = 0; t < UT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int unit = (w * UT + t) * 16 + lq + 4 * r;
+                const double b = net[nl.b2() + unit];
+                const double z0 = d[t][0][r] + b, z1 = d[t][1][r] + b;
+                sh_h[unit][lr] = z0 > 0 ? z0 : 0.0;
+                sh_h[unit][16 + lr] = z1 > 0 ? z1 : 0.0;
+            }
+    } else {
     double acc[UN][TM];
     // one batch of KB inputs: `first` starts the sums with the product of input 0 (no addition to a zero)
     auto batch = [&](int k0, auto first) {
@@ -1788,6 +1832,7 @@ __global__ __launch_bounds__(MLP_TILE_THREADS) void mlp_tile_kernel(const MlpArg
             const double z = acc[u][r] + b;
             sh_h[u0 + u][g * TM + r] = z > 0 ? z : 0.0;
         }
+    }
     }
     __syncthreads();
     {   // third layer: thread = (state, two of the eight outputs)
