@@ -345,25 +345,83 @@ def _free_port():
     return port
 
 
-def launch_ranks(n_ranks, argv):
+def visible_gpu_count():
+    """GPUs this machine offers, counted WITHOUT loading the HIP runtime: the kernel driver lists its nodes under
+    /sys/class/kfd/kfd/topology/nodes, a GPU being a node with a non-zero gfx_target_version (CPUs have 0); a
+    *_VISIBLE_DEVICES list in the environment caps the figure.  An upper bound only -- every rank still checks the
+    device it is given -- but enough to refuse `--gpus N` on a machine that cannot hold N ranks before any starts."""
+    import glob
+    seen = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(path) as f:
+                for line in f:
+                    key, _, val = line.partition(" ")
+                    if key == "gfx_target_version" and val.strip() not in ("", "0"):
+                        seen += 1
+        except OSError:
+            pass
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        lst = os.environ.get(var)
+        if lst is not None:
+            seen = min(seen, len([x for x in lst.split(",") if x.strip() != ""]))
+    return seen
+
+
+def launch_ranks(n_ranks, argv, poll_s=0.05, grace_s=5.0):
     """Starts `n_ranks` copies of this script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
-    environment, exactly what torch.distributed.run would set), waits for all of them and returns the largest
-    exit status.  The parent never touches the GPU: the children are plain child processes, not an exec of a
-    process that holds a device."""
+    environment, exactly what torch.distributed.run would set) and supervises them: all children are polled together;
+    when one ends with a non-zero status the others -- which would otherwise sit in the rendezvous or in a collective
+    until its timeout -- are terminated (SIGTERM, SIGKILL after `grace_s`), the failing rank and its status are named
+    on stderr and that status is returned.  Returns 0 when every rank ended with 0.  The parent imports neither torch
+    nor the engine and makes no HIP call: the children are plain child processes of a process that never held a GPU."""
+    import signal
     import subprocess
     port = _free_port()
     procs = []
-    for r in range(n_ranks):
-        env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
-    worst = 0
-    for p in procs:
-        rc = p.wait()
-        worst = max(worst, abs(rc))
-    return worst
+    try:
+        for r in range(n_ranks):
+            env = dict(os.environ)
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+        failed = None
+        live = set(range(n_ranks))
+        while live and failed is None:
+            for r in sorted(live):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                live.discard(r)
+                if rc != 0 and failed is None:
+                    failed = (r, rc)
+            if live and failed is None:
+                time.sleep(poll_s)
+        if failed is None:
+            return 0
+        r, rc = failed
+        why = ("killed by signal %d" % -rc) if rc < 0 else ("exit status %d" % rc)
+        sys.stderr.write("bench.py: rank %d of %d failed (%s); stopping the other %d rank(s)\n"
+                         % (r, n_ranks, why, len(live)))
+        sys.stderr.flush()
+        return abs(rc) if abs(rc) < 256 else 1
+    finally:
+        # whatever way this function is left (a failed rank, an exception, a signal turned into KeyboardInterrupt):
+        # no child survives the launcher
+        rest = [p for p in procs if p.poll() is None]
+        for p in rest:
+            try:
+                p.send_signal(signal.SIGTERM)
+            except OSError:
+                pass
+        deadline = time.monotonic() + grace_s
+        for p in rest:
+            try:
+                p.wait(timeout=max(0.0, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
 
 
 def run_rehearsal(args, rank, world):
@@ -373,8 +431,13 @@ def run_rehearsal(args, rank, world):
     import numpy as np
     import torch
     import torch.distributed as dist
+    import datetime
     from epidemicsimulator_amd.dist import first_min, gather_surface_strided, strided_bounds
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if args.fail_rank == rank and args.fail_at == "start":
+        raise SystemExit(7)            # a rank that dies before the rendezvous (bad device, failed RCCL start-up)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.rendezvous_timeout))
+    if args.fail_rank == rank and args.fail_at == "collective":
+        os._exit(9)                    # a rank that dies with its peers already inside a collective
     if dist.get_world_size() != args.gpus:
         raise SystemExit("bench.py: process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
     G = 4096
@@ -412,20 +475,34 @@ def main():
                     help="threads of the cpu_baseline leg; 0 = the host cores this process may use")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="multi-rank plumbing only, over gloo, no engine (see run_rehearsal)")
+    ap.add_argument("--fail-rank", type=int, default=-1,
+                    help="rehearsal only: this rank dies on purpose (launcher supervision test)")
+    ap.add_argument("--fail-at", choices=("start", "collective"), default="start",
+                    help="rehearsal only: where --fail-rank dies: before the rendezvous or after it, with its peers in "
+                         "the all-gather")
+    ap.add_argument("--rendezvous-timeout", type=float, default=180.0,
+                    help="seconds a rank waits in init_process_group / a collective for its peers before giving up")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
 
     # ---- N ranks, one per GPU.  Launched by torch.distributed.run the environment already names this process's
     # rank; launched plainly with --gpus N > 1 this process only starts the N ranks and waits for them.
+    # The launcher imports neither torch nor the engine: it must never bring up the HIP runtime, because the ranks
+    # are started from it and a process that holds a GPU may not start others on this kind of machine.
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         if not args.rehearse_cpu:
-            import torch   # device_count() does not initialise the GPU in this process
-            seen = torch.cuda.device_count()
+            seen = visible_gpu_count()
             if seen < args.gpus:
                 raise SystemExit("bench.py: --gpus %d needs %d HIP devices, %d visible on this machine: refusing to "
                                  "run fewer ranks than asked for" % (args.gpus, args.gpus, seen))
-        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+        import signal
+        signal.signal(signal.SIGTERM, lambda *_: sys.exit(143))   # so that launch_ranks' clean-up runs
+        rc = launch_ranks(args.gpus, sys.argv[1:])
+        if os.environ.get("EPI_BENCH_LAUNCHER_REPORT") == "1":
+            heavy = sorted(m for m in ("torch", "numpy", "epidemicsimulator_amd") if m in sys.modules)
+            sys.stderr.write("bench.py launcher: modules loaded in the parent: %s\n" % (heavy or "none of torch/numpy/engine"))
+        raise SystemExit(rc)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -453,7 +530,9 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        import datetime
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(seconds=args.rendezvous_timeout))
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
         world = dist.get_world_size()
