@@ -336,6 +336,69 @@ def run_learn(args, rank, local_rank, world, use_dist):
         dist.destroy_process_group()
 
 
+def run_multi_in_process(args):
+    """--multi-in-process: the same sweep driven from ONE process over several GPUs through the library's own
+    multi-device path (epi_grid_multi_*: an engine and a stream per share, RCCL all-gather called from C), printing the
+    same JSON line, so that it can be put on the scaling curve next to the one-process-per-GPU path.  --multi-devices
+    names the device of every share (default 0 .. N-1; a device may be named more than once)."""
+    import epidemicsimulator_amd as E
+    from epidemicsimulator_amd import synth
+    devices = [int(x) for x in args.multi_devices.split(",")] if args.multi_devices else list(range(args.gpus))
+    seen = E.lib().epi_device_count()
+    if seen < 1 or max(devices) >= seen:
+        raise SystemExit("bench.py: --multi-in-process over devices %s needs %d HIP devices, %d visible"
+                         % (devices, max(devices) + 1, seen))
+    wl = synth.workload(args.workload)
+    if args.workload.lower() in ("c5", "learn"):
+        raise SystemExit("bench.py: --multi-in-process drives the calibration sweep (c1..c4)")
+    n, T = len(wl["countries"]), wl["steps"]
+    nb, nt = len(wl["betas"]), len(wl["travel"])
+    G = nb * nt
+    base = synth.base_state(T)
+    m = E.MultiGridEngine(E.HyperParams(), T, base, wl["seed_idx"], [c.pop for c in wl["countries"]], wl["conn"],
+                          wl["profiles"], wl["betas"], wl["travel"], wl["t_arrive"], wl["t_peak"], True, devices=devices)
+    ranks, slots = m.ranks()
+    for _ in range(args.warmup):
+        m.run(want_metrics=False)
+    m.set_timing(True)
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(args.steps):
+        out = m.run(want_metrics=False)          # synchronous: returns with the surface on the host and the first minimum
+    elapsed = time.perf_counter() - t0
+    tm = m.times()
+    peer = m.peer_access().tolist()
+    m.close()
+    total_cs = float(G) * n * T * args.steps
+    bpcs = algorithmic_bytes_per_country_step(n, wl["conn"])
+    share_ms = [float(x) / max(1, args.steps) for x in tm["share_kernel_ms"]]
+    slowest = max(share_ms) if share_ms else 0.0
+    per_share_cs = [float(len(range(k, G, len(devices)))) * n * T for k in range(len(devices))]
+    k_slow = share_ms.index(slowest) if share_ms else 0
+    achieved = per_share_cs[k_slow] * bpcs / (slowest * 1e-3) / 1e9 if slowest > 0 else 0.0
+    line = {
+        "metric": "country-steps/sec (calibration grid, whole node)",
+        "value": total_cs / elapsed, "unit": "country-steps/s", "n_gpus": ranks, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s: %d countries, %dx%d beta x travel grid, %d-step episodes, %s" % (
+            wl["name"], n, nb, nt, T, "CSR graph" if isinstance(wl["conn"], tuple) else "dense graph"),
+            "grid_points": G, "country_steps_per_step": G * n * T,
+            "parallelism": "one process, %d interleaved shares on devices %s (%d distinct), RCCL all-gather from C "
+                           "(epi_grid_multi_run)" % (len(devices), devices, ranks),
+            "best_idx": int(out["best_idx"]), "best_loss": float(out["best_loss"]), "rccl_ranks": ranks,
+            "share_slots_per_rank": slots, "kernel_ms_per_step_by_share": [round(x, 3) for x in share_ms],
+            "all_gather_ms_per_step": tm["gather_ms"] / max(1, args.steps),
+            "host_ms_per_step_inside_the_library": tm["wall_ms"] / max(1, args.steps), "peer_access": peer},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "episode kernels of the slowest share (%d)" % k_slow,
+                     "algorithmic_bytes_per_country_step": bpcs,
+                     "note": "shares that sit on one device run concurrently, so a share's kernel time there includes "
+                             "waiting for the others; with one share per device it is that device's kernel time"},
+    }
+    print(json.dumps(line), flush=True)
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -475,6 +538,11 @@ def main():
                     help="threads of the cpu_baseline leg; 0 = the host cores this process may use")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="multi-rank plumbing only, over gloo, no engine (see run_rehearsal)")
+    ap.add_argument("--multi-in-process", action="store_true",
+                    help="one process drives --gpus N devices through epi_grid_multi_* (RCCL from C) instead of one "
+                         "rank per GPU")
+    ap.add_argument("--multi-devices", default="",
+                    help="with --multi-in-process: comma-separated device of every share (default 0..N-1)")
     ap.add_argument("--fail-rank", type=int, default=-1,
                     help="rehearsal only: this rank dies on purpose (launcher supervision test)")
     ap.add_argument("--fail-at", choices=("start", "collective"), default="start",
@@ -488,6 +556,11 @@ def main():
 
     # ---- N ranks, one per GPU.  Launched by torch.distributed.run the environment already names this process's
     # rank; launched plainly with --gpus N > 1 this process only starts the N ranks and waits for them.
+    if args.multi_in_process:
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+            raise SystemExit("bench.py: --multi-in-process is one process for all devices; do not launch it as several ranks")
+        return run_multi_in_process(args)
+
     # The launcher imports neither torch nor the engine: it must never bring up the HIP runtime, because the ranks
     # are started from it and a process that holds a GPU may not start others on this kind of machine.
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

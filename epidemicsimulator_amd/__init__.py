@@ -1098,6 +1098,7 @@ class MultiGridEngine:
         d, _keep = _grid_desc(hp, steps, base, seed_idx, pops, conn, profiles, self.betas, self.travel, t_arrive, t_peak,
                               heterogeneous, 0)
         dev = i32(list(devices))
+        self.n_shares = len(dev)
         h = lib().epi_grid_multi_create(C.byref(d), ptr(dev, C.c_int32), C.c_int32(len(dev)))
         if not h:
             _capi.raise_last(_capi.EPI_ERR_DEVICE)
@@ -1128,6 +1129,25 @@ class MultiGridEngine:
         check(lib().epi_grid_multi_run(self._h, loss.ctypes.data, arr.ctypes.data if want_metrics else None,
                                        pk.ctypes.data if want_metrics else None, C.byref(bi), C.byref(bl)))
         return dict(loss=loss[:self.G], arrival=arr, peak=pk, best_idx=bi.value, best_loss=bl.value)
+
+    def set_timing(self, on: bool):
+        check(lib().epi_grid_multi_set_timing(self._h, int(on)))
+
+    def times(self):
+        """dict(share_kernel_ms[n_shares], gather_ms, wall_ms, runs) since set_timing(True)."""
+        sk = np.zeros(self.n_shares); g = C.c_double(0); w = C.c_double(0); r = C.c_int64(0)
+        check(lib().epi_grid_multi_times(self._h, ptr(sk, C.c_double), C.byref(g), C.byref(w), C.byref(r)))
+        return dict(share_kernel_ms=sk, gather_ms=g.value, wall_ms=w.value, runs=r.value)
+
+    def peer_access(self) -> np.ndarray:
+        r, _ = self.ranks()
+        m = np.zeros((r, r), dtype=np.uint8)
+        check(lib().epi_grid_multi_peer_access(self._h, ptr(m, C.c_uint8)))
+        return m
+
+    def inject_failure(self, share: int):
+        """Test hook: the next run() fails at this share's enqueue."""
+        check(lib().epi_grid_multi_inject_failure(self._h, int(share)))
 
 
 def grid_argmin(loss) -> Tuple[int, float]:

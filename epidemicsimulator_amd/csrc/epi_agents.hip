@@ -666,6 +666,7 @@ EPI_API int32_t epi_agents_observe_world(epi_agents* g, epi_world* w) {
                        g->file_dst.on_device<long long>(), v);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(g->stream));  // the staging array is free again
+    world_transition_consumed(w);               // a second call without a step in between must not file it again
     return EPI_OK;
 }
 

@@ -559,7 +559,12 @@ struct epi_grid {
     double kernel_ms = 0.0;
     long long kernel_launches = 0;
     long long kernel_country_steps = 0;
-    DevBuf stats;  // search statistics, allocated when EPI_STATS is set in the environment
+    DevBuf stats;  // search statistics, allocated at creation when EPI_STATS is set in the environment
+    // epi_grid_run_noalloc: the per-episode state lives in the per-GPU fixed work area, which every handle on that
+    // GPU shares -- the error table does not: it is this handle's own (allocated at creation, sized for the most
+    // episodes one such call can take), so another handle's later call cannot overwrite what status() will read
+    DevBuf noalloc_err;
+    int noalloc_max_episodes = 0;
 };
 
 struct epi_world {
@@ -1023,6 +1028,23 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
         HIP_TRY(G->has_peak.upload(hk));
     }
     stamp("network and targets");
+    // everything a later call must not do: kernel attributes of this device, the statistics block, the error table of
+    // the allocation-free entry point
+    HIP_TRY(prepare_device_kernels());
+    if (getenv("EPI_STATS")) {
+        HIP_TRY(G->stats.ensure(64 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(G->stats.p, 0, 64 * sizeof(unsigned long long)));
+    }
+    {
+        const size_t per_episode = scratch_need(1, (size_t)npad, G->graph.sparse);
+        const size_t fit = kNoallocScratchBytes / per_episode;   // an upper bound: sections are padded per call, not per episode
+        const size_t grid_points = (size_t)std::max(1, d->n_beta * d->n_travel);
+        G->noalloc_max_episodes = (int)std::min(fit, grid_points);
+        if (G->noalloc_max_episodes > 0) {
+            HIP_TRY(G->noalloc_err.ensure((size_t)G->noalloc_max_episodes * 4 * sizeof(int32_t)));
+            HIP_TRY(hipMemset(G->noalloc_err.p, 0, (size_t)G->noalloc_max_episodes * 4 * sizeof(int32_t)));
+        }
+    }
     return EPI_OK;
 }
 
@@ -1129,14 +1151,19 @@ EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, doub
 }
 
 // Enqueues init -> episode segments (split around the argmax-Q steps) -> loss for the given grid points on `s`,
-// with the per-episode state in `wp`.  Allocates nothing unless `timed` (HIP events) or EPI_STATS asks for it.
+// with the per-episode state in `wp`.  Allocates nothing unless `may_allocate` and timing is on (HIP events per launch).
 static int32_t grid_enqueue(epi_grid* g, int32_t g_begin, int32_t g_stride, int32_t g_count, const WorkPtrs& wp, double* d_loss,
                             int32_t* d_arr, double* d_pk, hipStream_t s, bool may_allocate) {
     const int n = g->n, npad = g->npad;
     int32_t rc;
     // one outstanding run per handle: the work buffers and the error table are shared, so an earlier run that was
-    // only enqueued is waited for and its status collected before they are overwritten (its failure is returned here)
+    // only enqueued is waited for and its status collected before they are overwritten (its failure is returned here).
+    // The allocation-free entry point may not wait (its callers include code under stream capture, where a
+    // device-wide wait is illegal): it refuses instead.
     if (g->pending) {
+        if (!may_allocate)
+            return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_run_noalloc: this handle still holds an uncollected run: call epi_grid_status() first "
+                                              "(this entry point never waits on the device itself)");
         rc = epi_grid_status(g);
         if (rc) return rc;
     }
@@ -1168,13 +1195,7 @@ static int32_t grid_enqueue(epi_grid* g, int32_t g_begin, int32_t g_stride, int3
     ea.actions = g->actions.as<int8_t>(); ea.act_t0 = 0;
     ea.noise = g->noise.as<double>(); ea.noise_t0 = 0;
     ea.st = ia.st; ea.cap = ia.cap; ea.tcur = ia.tcur; ea.arrival = ia.arrival; ea.peak = ia.peak; ea.err = ia.err;
-    if (may_allocate && getenv("EPI_STATS")) {
-        if (!g->stats.p) {
-            HIP_TRY(g->stats.ensure(64 * sizeof(unsigned long long)));
-            HIP_TRY(hipMemset(g->stats.p, 0, 64 * sizeof(unsigned long long)));
-        }
-        ea.stats = g->stats.as<unsigned long long>();
-    }
+    if (g->stats.p) ea.stats = g->stats.as<unsigned long long>();
     auto episode = [&](const EpisodeArgs& e) -> int32_t {
         if (may_allocate) return timed_episode(g, e, s);
         HIP_TRY(launch_episode(e, s));
@@ -1285,7 +1306,10 @@ EPI_API int32_t epi_grid_run_noalloc(epi_grid* g, int32_t g_begin, int32_t g_str
     rc = scratch_base(g->device, &base);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(g->device));
-    const WorkPtrs wp = carve_scratch(base, (size_t)g_count, (size_t)g->npad, g->graph.sparse);
+    WorkPtrs wp = carve_scratch(base, (size_t)g_count, (size_t)g->npad, g->graph.sparse);
+    if (g_count > g->noalloc_max_episodes)   // cannot happen after the size check above; keeps the table's bound explicit
+        return fail(EPI_ERR_UNSUPPORTED, "epi_grid_run_noalloc: %d episodes, the handle's error table holds %d", g_count, g->noalloc_max_episodes);
+    wp.err = g->noalloc_err.as<int32_t>();   // the handle's own table, not the shared area's
     return grid_enqueue(g, g_begin, g_stride, g_count, wp, loss_dev, arrival_dev, peak_dev, static_cast<hipStream_t>(stream), false);
 }
 
@@ -1402,6 +1426,7 @@ static int32_t world_build(epi_world* Wd, const epi_world_desc* d) {
     }
     rc = use_device(d->device);
     if (rc) return rc;
+    HIP_TRY(prepare_device_kernels());
     Wd->device = d->device;
     Wd->n = d->n; Wd->batch = d->batch; Wd->seed_idx = d->seed_idx; Wd->validate = d->validate;
     Wd->base = d->base;
@@ -1487,6 +1512,7 @@ EPI_API int32_t epi_world_destroy(epi_world* w) {
 EPI_API int32_t epi_world_reset(epi_world* w) {
     if (!w) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_reset: null handle");
     HIP_TRY(hipSetDevice(w->device));
+    w->have_tr = false;   // the kept transition belongs to states that no longer exist
     return world_init_states(w);
 }
 
@@ -1545,6 +1571,7 @@ EPI_API int32_t epi_world_set_states(epi_world* w, const epi_state* in) {
     HIP_TRY(hipMemcpy(w->work.st.p, st.data(), st.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(w->work.tcur.p, tc.data(), tc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(w->work.cap.p, cap.data(), cap.size() * sizeof(double), hipMemcpyHostToDevice));
+    w->have_tr = false;   // the kept transition's s2 planes were just overwritten
     return EPI_OK;
 }
 
@@ -1708,6 +1735,7 @@ EPI_API int32_t epi_world_rollout_greedy(epi_world* w, epi_agents* agents, int32
         return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_rollout_greedy: pass the nodes' agents or call epi_world_set_mlp first");
     }
     HIP_TRY(hipSetDevice(w->device));
+    w->have_tr = false;   // stepOneGreedy observes nothing (WorldToy.scala:172-235): no transition is kept past this call
     hipStream_t s = nullptr;
     // Validation.arrivalTime / peakI count from the first step of this call; the error table starts clean
     HIP_TRY(hipMemsetAsync(w->work.arrival.p, 0xff, cells * sizeof(int32_t), s));
@@ -1814,6 +1842,9 @@ int32_t world_transition_view(epi_world* w, WorldTransitionView* v) {
     v->st = w->work.st.as<int32_t>(); v->cap = w->work.cap.as<double>();
     v->reward = w->reward_dev.as<double>(); v->act = w->act_dev.as<int8_t>();
     return EPI_OK;
+}
+void world_transition_consumed(epi_world* w) {
+    if (w) w->have_tr = false;
 }
 }  // namespace epi
 

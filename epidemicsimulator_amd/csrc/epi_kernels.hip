@@ -1,6 +1,8 @@
 // HIP kernels (gfx950) for the metapopulation step and the calibration sweep.
 // Compiled with -ffp-contract=off: see epi_device.hpp.
 #include "epi_kernels.hpp"
+
+#include <atomic>
 #include "sort_net.hpp"
 
 // Phase timers of the sparse kernel: compiled in with -DEPI_CSR_TIMERS (they cost registers), read with EPI_STATS=1.
@@ -1145,8 +1147,7 @@ size_t csr_lds_bytes(int n) { return (((size_t)n * 8 + 15) & ~(size_t)15) + 4 * 
 template <int DMAX>
 static hipError_t launch_csr(const EpisodeArgs& a, hipStream_t s) {
     const size_t lds = csr_lds_bytes(a.n);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&episode_csr_kernel<DMAX>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = prepare_device_kernels();   // a flag test after the first call on a device
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(episode_csr_kernel<DMAX>, dim3((unsigned)a.count), dim3(kCsrThreads), lds, s, a);
     return hipGetLastError();
@@ -1902,9 +1903,8 @@ template <int ROWS>
 static hipError_t launch_mlp_rows(const MlpArgs& a, int live, hipStream_t s) {
     const int H = a.nl.H;
     const size_t lds = mlp_lds_bytes(H, ROWS);
-    if (lds > 48 * 1024) {   // the attribute is kept per device: set it where it is needed
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_greedy_kernel<ROWS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_lds_bytes(MLP_MAXH, ROWS));
+    if (lds > 48 * 1024) {
+        hipError_t e = prepare_device_kernels();   // a flag test after the first call on a device
         if (e != hipSuccess) return e;
     }
     const dim3 grid((unsigned)((live + ROWS - 1) / ROWS), a.per_country ? (unsigned)a.n : 1u);
@@ -2309,6 +2309,35 @@ hipError_t launch_gravity(const GravityArgs& a, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
     hipLaunchKernelGGL(gravity_rows_kernel, dim3((unsigned)a.n), dim3(256), 0, s, a);
     return hipGetLastError();
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Kernel attributes of the current device.  The limit on dynamic LDS is a per-device property of a kernel; the
+// kernels that may ask for more than the 48 KB default get the largest size they can ever be launched with, once
+// per device (handle creation calls this, so no launch path has to), and every later call is one flag test.
+// ---------------------------------------------------------------------------------------------
+hipError_t prepare_device_kernels() {
+    constexpr int kMaxDevices = 64;
+    static std::atomic<bool> ready[kMaxDevices];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    if (ready[dev].load(std::memory_order_acquire)) return hipSuccess;
+    auto lds_limit = [](const void* fn, size_t bytes) {
+        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    };
+    if ((e = lds_limit(reinterpret_cast<const void*>(&episode_csr_kernel<16>), kMaxLdsBytes)) != hipSuccess) return e;
+    if ((e = lds_limit(reinterpret_cast<const void*>(&episode_csr_kernel<24>), kMaxLdsBytes)) != hipSuccess) return e;
+    if ((e = lds_limit(reinterpret_cast<const void*>(&episode_csr_kernel<kLaneSlots>), kMaxLdsBytes)) != hipSuccess) return e;
+    if ((e = lds_limit(reinterpret_cast<const void*>(&mlp_greedy_kernel<1>), mlp_lds_bytes(MLP_MAXH, 1))) != hipSuccess) return e;
+    if ((e = lds_limit(reinterpret_cast<const void*>(&mlp_greedy_kernel<2>), mlp_lds_bytes(MLP_MAXH, 2))) != hipSuccess) return e;
+    if ((e = lds_limit(reinterpret_cast<const void*>(&mlp_greedy_kernel<4>), mlp_lds_bytes(MLP_MAXH, 4))) != hipSuccess) return e;
+    if ((e = lds_limit(reinterpret_cast<const void*>(&mlp_greedy_kernel<8>), mlp_lds_bytes(MLP_MAXH, 8))) != hipSuccess) return e;
+    if ((e = lds_limit(reinterpret_cast<const void*>(&mlp_greedy_kernel<MLP_MAXROWS>), mlp_lds_bytes(MLP_MAXH, MLP_MAXROWS))) != hipSuccess) return e;
+    ready[dev].store(true, std::memory_order_release);
+    return hipSuccess;
 }
 
 }  // namespace epi

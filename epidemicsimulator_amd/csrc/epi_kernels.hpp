@@ -259,6 +259,8 @@ struct WorldTransitionView {
 struct epi_world;
 namespace epi {
 int32_t world_transition_view(epi_world* w, WorldTransitionView* v);
+// Marks the world's kept transition as filed: the next epi_agents_observe_world needs a new step first.
+void world_transition_consumed(epi_world* w);
 
 // Device view of the networks an epi_agents handle holds (epi_agents.hip).
 struct AgentsNetView {
@@ -288,6 +290,8 @@ hipError_t launch_gravity_csr(const GravityCsrArgs& a, hipStream_t s);
 hipError_t launch_gravity(const GravityArgs& a, hipStream_t s);
 hipError_t launch_world_pack(const WorldIoArgs& a, hipStream_t s);
 hipError_t launch_world_unpack(const WorldIoArgs& a, hipStream_t s);
+// Sets, once per device, the dynamic-LDS limits of the kernels that may exceed the default (current device).
+hipError_t prepare_device_kernels();
 hipError_t launch_episode(const EpisodeArgs& a, hipStream_t s);
 hipError_t launch_init(const InitArgs& a, hipStream_t s);
 hipError_t launch_loss(const LossArgs& a, hipStream_t s);

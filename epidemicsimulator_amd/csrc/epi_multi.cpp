@@ -17,6 +17,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -93,6 +94,7 @@ struct RankBuf {
     double* full = nullptr;   // [ranks][slots][per]: every piece, after the all-gather
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;   // around the all-gather on `stream` while timing is on
 };
 
 }  // namespace
@@ -102,7 +104,12 @@ struct epi_grid_multi {
     std::vector<Share> shares;
     std::vector<RankBuf> ranks;
     std::vector<double> host_full;
-    double last_enqueue_ms = 0.0;
+    std::vector<uint8_t> peer;    // [ranks][ranks]: hipDeviceCanAccessPeer(device of rank a, device of rank b); diagnostics only
+    int inject_fail_share = -1;   // test hook: the next run fails when it reaches this share's enqueue
+    // timing (epi_grid_multi_set_timing): per-share kernel time comes from the shares' own engines
+    bool timing = false;
+    double gather_ms = 0.0, wall_ms = 0.0;
+    long long runs = 0;
 };
 
 static int32_t multi_free(epi_grid_multi* m) {
@@ -121,6 +128,8 @@ static int32_t multi_free(epi_grid_multi* m) {
         (void)hipSetDevice(r.device);
         if (r.send) (void)hipFree(r.send);
         if (r.full) (void)hipFree(r.full);
+        if (r.t0) (void)hipEventDestroy(r.t0);
+        if (r.t1) (void)hipEventDestroy(r.t1);
         if (r.stream) (void)hipStreamDestroy(r.stream);
     }
     delete m;
@@ -205,10 +214,34 @@ EPI_API epi_grid_multi* epi_grid_multi_create(const epi_grid_desc* desc, const i
     if (nr != ncclSuccess) { fail(EPI_ERR_DEVICE, "ncclCommInitAll over %d devices: %s", n_ranks, R->GetErrorString(nr)); return nullptr; }
     for (int r = 0; r < n_ranks; ++r) m->ranks[(size_t)r].comm = comms[(size_t)r];
     m->host_full.resize(piece * m->slots * n_ranks);
+    // which pairs of devices reach each other's memory directly (xGMI / PCIe peer access): RCCL picks its transport
+    // itself, this table only lets a caller see what it had to work with
+    m->peer.assign((size_t)n_ranks * n_ranks, 0);
+    for (int a = 0; a < n_ranks; ++a)
+        for (int b = 0; b < n_ranks; ++b) {
+            int can = a == b ? 1 : 0;
+            if (a != b && hipDeviceCanAccessPeer(&can, distinct[(size_t)a], distinct[(size_t)b]) != hipSuccess) { can = 0; (void)hipGetLastError(); }
+            m->peer[(size_t)a * n_ranks + b] = (uint8_t)(can != 0);
+        }
     return m.release();
 }
 
 EPI_API int32_t epi_grid_multi_destroy(epi_grid_multi* m) { return multi_free(m); }
+
+// Waits for everything shares [0, upto) have enqueued and clears their pending status, so that a run that is given
+// up half way leaves no kernel running and no engine holding an uncollected run.  Errors are ignored: the caller
+// is already reporting one.
+static void multi_quiesce(epi_grid_multi* m, int upto) {
+    for (int k = 0; k < upto; ++k) {
+        Share& s = m->shares[(size_t)k];
+        if (hipSetDevice(s.device) != hipSuccess) continue;
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        if (s.grid && s.count > 0) (void)epi_grid_status(s.grid);
+    }
+    for (auto& rb : m->ranks)
+        if (hipSetDevice(rb.device) == hipSuccess && rb.stream) (void)hipStreamSynchronize(rb.stream);
+    (void)hipGetLastError();
+}
 
 EPI_API int32_t epi_grid_multi_run(epi_grid_multi* m, double* loss, int32_t* arrival, double* peak, int32_t* best_idx,
                                    double* best_loss) {
@@ -216,42 +249,100 @@ EPI_API int32_t epi_grid_multi_run(epi_grid_multi* m, double* loss, int32_t* arr
     Rccl* R = rccl();
     const int n_ranks = (int)m->ranks.size();
     const size_t piece = (size_t)std::max(1, m->per);
+    const auto wall0 = std::chrono::steady_clock::now();
+    // A failure below must not leave earlier shares running or pending: remember the calling thread's message,
+    // quiesce, put the message back (the clean-up's own calls overwrite it) and return the first status.
+    auto give_up = [&](int32_t rc, int enqueued) {
+        char msg[512];
+        epi_last_error(msg, sizeof msg);
+        multi_quiesce(m, enqueued);
+        return fail(rc, "%s", msg);
+    };
+#define MULTI_HIP(expr, enq)                                                                                   \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) { fail(EPI_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); return give_up(EPI_ERR_DEVICE, (enq)); } \
+    } while (0)
     // 1. every share's sweep, enqueued on its own stream, its loss piece written straight into its device's send buffer
     for (int k = 0; k < m->n_shares; ++k) {
         Share& s = m->shares[(size_t)k];
-        HIP_TRY(hipSetDevice(s.device));
+        MULTI_HIP(hipSetDevice(s.device), k);
+        if (m->inject_fail_share == k) {
+            m->inject_fail_share = -1;
+            fail(EPI_ERR_DEVICE, "share %d on device %d: failure injected by epi_grid_multi_inject_failure", k, s.device);
+            return give_up(EPI_ERR_DEVICE, k);
+        }
         if (s.count > 0) {
-            if (arrival && !s.arrival) HIP_TRY(hipMalloc((void**)&s.arrival, sizeof(int32_t) * (size_t)s.count * m->n));
-            if (peak && !s.peak) HIP_TRY(hipMalloc((void**)&s.peak, sizeof(double) * (size_t)s.count * m->n));
+            if (arrival && !s.arrival) MULTI_HIP(hipMalloc((void**)&s.arrival, sizeof(int32_t) * (size_t)s.count * m->n), k);
+            if (peak && !s.peak) MULTI_HIP(hipMalloc((void**)&s.peak, sizeof(double) * (size_t)s.count * m->n), k);
             int32_t rc = epi_grid_run_strided(s.grid, k, m->n_shares, s.count, m->ranks[(size_t)s.rank].send + (size_t)s.slot * piece,
                                               arrival ? s.arrival : nullptr, peak ? s.peak : nullptr, 1, s.stream);
-            if (rc) return rc;
+            if (rc) return give_up(rc, k + 1);
         }
-        HIP_TRY(hipEventRecord(s.done, s.stream));
+        MULTI_HIP(hipEventRecord(s.done, s.stream), k + 1);
     }
     // 2. one all-gather of the pieces: each device's exchange stream waits for that device's shares
     for (auto& s : m->shares) {
         RankBuf& rb = m->ranks[(size_t)s.rank];
-        HIP_TRY(hipSetDevice(rb.device));
-        HIP_TRY(hipStreamWaitEvent(rb.stream, s.done, 0));
+        MULTI_HIP(hipSetDevice(rb.device), m->n_shares);
+        MULTI_HIP(hipStreamWaitEvent(rb.stream, s.done, 0), m->n_shares);
     }
-    NCCL_TRY(R->GroupStart());
-    for (int r = 0; r < n_ranks; ++r) {
-        RankBuf& rb = m->ranks[(size_t)r];
-        NCCL_TRY(R->AllGather(rb.send, rb.full, piece * m->slots, ncclDouble, rb.comm, rb.stream));
+    if (m->timing)
+        for (auto& rb : m->ranks) {
+            MULTI_HIP(hipSetDevice(rb.device), m->n_shares);
+            MULTI_HIP(hipEventRecord(rb.t0, rb.stream), m->n_shares);
+        }
+    {
+        // an open group must be closed whatever happens inside it: the library is shared with every other user of
+        // RCCL in the process, and calls made while a group is open are only queued
+        ncclResult_t first = R->GroupStart();
+        if (first == ncclSuccess) {
+            for (int r = 0; r < n_ranks; ++r) {
+                RankBuf& rb = m->ranks[(size_t)r];
+                const ncclResult_t nr = R->AllGather(rb.send, rb.full, piece * m->slots, ncclDouble, rb.comm, rb.stream);
+                if (nr != ncclSuccess && first == ncclSuccess) first = nr;
+            }
+            const ncclResult_t ge = R->GroupEnd();
+            if (ge != ncclSuccess && first == ncclSuccess) first = ge;
+        }
+        if (first != ncclSuccess) {
+            fail(EPI_ERR_DEVICE, "all-gather of the loss pieces over %d devices: %s", n_ranks, R->GetErrorString(first));
+            return give_up(EPI_ERR_DEVICE, m->n_shares);
+        }
     }
-    NCCL_TRY(R->GroupEnd());
-    // 3. wait, collect every share's status, read the gathered surface from the first device
+    if (m->timing)
+        for (auto& rb : m->ranks) {
+            MULTI_HIP(hipSetDevice(rb.device), m->n_shares);
+            MULTI_HIP(hipEventRecord(rb.t1, rb.stream), m->n_shares);
+        }
+    // 3. wait, collect every share's status (all of them, so that no engine keeps an uncollected run; the first
+    //    failing share's status and message are the ones returned), read the gathered surface from the first device
     for (auto& rb : m->ranks) {
-        HIP_TRY(hipSetDevice(rb.device));
-        HIP_TRY(hipStreamSynchronize(rb.stream));
+        MULTI_HIP(hipSetDevice(rb.device), m->n_shares);
+        MULTI_HIP(hipStreamSynchronize(rb.stream), m->n_shares);
     }
-    for (int k = 0; k < m->n_shares; ++k) {
-        Share& s = m->shares[(size_t)k];
-        if (s.count == 0) continue;
-        int32_t rc = epi_grid_status(s.grid);
-        if (rc) return rc;
+    {
+        int32_t first_rc = EPI_OK;
+        char first_msg[512] = "";
+        for (int k = 0; k < m->n_shares; ++k) {
+            Share& s = m->shares[(size_t)k];
+            if (s.count == 0) continue;
+            const int32_t rc = epi_grid_status(s.grid);
+            if (rc && !first_rc) { first_rc = rc; epi_last_error(first_msg, sizeof first_msg); }
+        }
+        if (first_rc) return fail(first_rc, "%s", first_msg);
     }
+    if (m->timing) {
+        float worst = 0.f;
+        for (auto& rb : m->ranks) {
+            float ms = 0.f;
+            HIP_TRY(hipSetDevice(rb.device));
+            HIP_TRY(hipEventElapsedTime(&ms, rb.t0, rb.t1));
+            worst = std::max(worst, ms);
+        }
+        m->gather_ms += worst;
+    }
+#undef MULTI_HIP
     HIP_TRY(hipSetDevice(m->ranks[0].device));
     HIP_TRY(hipMemcpy(m->host_full.data(), m->ranks[0].full, sizeof(double) * m->host_full.size(), hipMemcpyDeviceToHost));
     std::vector<double> tmp;
@@ -277,7 +368,57 @@ EPI_API int32_t epi_grid_multi_run(epi_grid_multi* m, double* loss, int32_t* arr
             }
         }
     }
-    return epi_grid_argmin(loss, m->G, best_idx, best_loss);
+    const int32_t rc = epi_grid_argmin(loss, m->G, best_idx, best_loss);
+    if (m->timing) {
+        m->wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        m->runs += 1;
+    }
+    return rc;
+}
+
+EPI_API int32_t epi_grid_multi_set_timing(epi_grid_multi* m, int32_t on) {
+    if (!m) return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_multi_set_timing: null handle");
+    for (auto& s : m->shares) {
+        const int32_t rc = epi_grid_set_timing(s.grid, on);
+        if (rc) return rc;
+    }
+    for (auto& rb : m->ranks) {
+        HIP_TRY(hipSetDevice(rb.device));
+        if (on && !rb.t0) {
+            HIP_TRY(hipEventCreate(&rb.t0));
+            HIP_TRY(hipEventCreate(&rb.t1));
+        }
+    }
+    m->timing = on != 0;
+    m->gather_ms = m->wall_ms = 0.0;
+    m->runs = 0;
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_grid_multi_times(epi_grid_multi* m, double* share_kernel_ms, double* gather_ms, double* wall_ms, int64_t* runs) {
+    if (!m) return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_multi_times: null handle");
+    for (int k = 0; k < m->n_shares && share_kernel_ms; ++k) {
+        double ms = 0.0;
+        const int32_t rc = epi_grid_kernel_time(m->shares[(size_t)k].grid, &ms, nullptr, nullptr);
+        if (rc) return rc;
+        share_kernel_ms[k] = ms;
+    }
+    if (gather_ms) *gather_ms = m->gather_ms;
+    if (wall_ms) *wall_ms = m->wall_ms;
+    if (runs) *runs = m->runs;
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_grid_multi_peer_access(const epi_grid_multi* m, uint8_t* can_access) {
+    if (!m || !can_access) return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_multi_peer_access: null argument");
+    std::copy(m->peer.begin(), m->peer.end(), can_access);
+    return EPI_OK;
+}
+
+EPI_API int32_t epi_grid_multi_inject_failure(epi_grid_multi* m, int32_t share) {
+    if (!m || share < -1 || share >= m->n_shares) return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_multi_inject_failure: share %d of %d", share, m ? m->n_shares : 0);
+    m->inject_fail_share = share;
+    return EPI_OK;
 }
 
 EPI_API int32_t epi_grid_multi_ranks(const epi_grid_multi* m, int32_t* n_ranks, int32_t* slots_per_rank) {

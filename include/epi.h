@@ -182,17 +182,21 @@ int32_t epi_grid_run(epi_grid *g, int32_t g_begin, int32_t g_count, double *loss
  * beta row cost about the same, episodes of different rows do not. */
 int32_t epi_grid_run_strided(epi_grid *g, int32_t g_begin, int32_t g_stride, int32_t g_count, double *loss,
                              int32_t *arrival, double *peak, int32_t out_on_device, void *stream);
-/* No counterpart in the reference: for callers that cannot allocate device memory -- code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc.  The sweep of epi_grid_run_strided with
- * out_on_device != 0 (same kernels, same results), but the per-episode state lives in a fixed 32 MiB device array
- * that the library holds on every GPU it runs on until the process ends, and the call allocates and frees
- * nothing (no hipMalloc / hipFree / events).  loss_dev[g_count] is device memory on the handle's device;
- * arrival_dev[g_count][n] and peak_dev[g_count][n] are optional device memory.  The work is enqueued on `stream`;
- * epi_grid_status() collects its status.  Limit: g_count episodes of the world's padded width must fit the
- * array (41 bytes per padded country and episode plus 16 per episode, 57 for sparse graphs: up to 798 episodes
- * of 1,000 countries, 3,192 of 200, 29 of a 20,000-patch world) -- larger requests return EPI_ERR_UNSUPPORTED
- * and run nothing.  All calls on one GPU share the array: calls that overlap in time on one GPU race (calls on one
- * stream are ordered and safe); it is overwritten from the start by every call. */
+/* No counterpart in the reference: for callers that cannot allocate device memory -- tight serving loops,
+ * harnesses that forbid hipMalloc, code that records the sweep under stream capture.  The sweep of
+ * epi_grid_run_strided with out_on_device != 0 (same kernels, same results), but the per-episode state lives in a
+ * fixed 32 MiB device array that the library holds on every GPU it runs on until the process ends, and the call
+ * allocates and frees nothing (no hipMalloc / hipFree / events), sets no kernel attribute, reads no environment
+ * variable and never waits on the device: it only enqueues kernels on `stream`.  loss_dev[g_count] is device
+ * memory on the handle's device; arrival_dev[g_count][n] and peak_dev[g_count][n] are optional device memory.
+ * epi_grid_status() collects the run's status from the handle's own error table (allocated by epi_grid_create).
+ * A handle holds one outstanding run: while one is uncollected this entry point returns EPI_ERR_BAD_ARGUMENT and
+ * enqueues nothing -- call epi_grid_status() first (outside any capture: it waits for the device).
+ * Limit: g_count episodes of the world's padded width must fit the array (41 bytes per padded country and episode
+ * plus 16 per episode, 57 for sparse graphs: up to 798 episodes of 1,000 countries, 3,192 of 200, 29 of a
+ * 20,000-patch world) -- larger requests return EPI_ERR_UNSUPPORTED and run nothing.  All calls on one GPU share
+ * the array: calls that overlap in time on one GPU race, whatever the handle (calls on one stream are ordered and
+ * safe, and each handle's status stays its own); it is overwritten from the start by every call. */
 int32_t epi_grid_run_noalloc(epi_grid *g, int32_t g_begin, int32_t g_stride, int32_t g_count, double *loss_dev,
                              int32_t *arrival_dev, double *peak_dev, void *stream);
 /* Waits for the last enqueued run and returns its status (first failing grid point wins).  A handle holds one
@@ -224,8 +228,25 @@ epi_grid_multi *epi_grid_multi_create(const epi_grid_desc *desc, const int32_t *
  * minimum.  Synchronous.  May be called repeatedly (tables, engines and the communicator are reused). */
 int32_t epi_grid_multi_run(epi_grid_multi *m, double *loss, int32_t *arrival, double *peak, int32_t *best_idx,
                            double *best_loss);
+/* A run that fails -- a share's enqueue, the all-gather, or a device-side check of any share (mass, Int range:
+ * the first failing share's status and message are returned) -- waits for everything already enqueued and collects
+ * every share's status before it returns, so the handle can be run again. */
 /* Communicator size (distinct devices) and the number of share slots each rank contributes to the all-gather. */
 int32_t epi_grid_multi_ranks(const epi_grid_multi *m, int32_t *n_ranks, int32_t *slots_per_rank);
+/* Measurement hooks (no counterpart in the reference).  With timing on, every share's episode launches are timed as
+ * by epi_grid_set_timing and the all-gather is bracketed by HIP events on every device's exchange stream.
+ * epi_grid_multi_times: share_kernel_ms[n_dev] = each share's summed episode-kernel time, gather_ms = the summed
+ * all-gather time (per run the slowest device's, which includes waiting for the slowest share), wall_ms = the
+ * summed host time of the epi_grid_multi_run calls, runs = their number, all since timing was switched on. */
+int32_t epi_grid_multi_set_timing(epi_grid_multi *m, int32_t on);
+int32_t epi_grid_multi_times(epi_grid_multi *m, double *share_kernel_ms, double *gather_ms, double *wall_ms,
+                             int64_t *runs);
+/* Diagnostics: can_access[n_ranks][n_ranks], entry (a, b) = 1 when the device of rank a can map the memory of the
+ * device of rank b (hipDeviceCanAccessPeer; 1 on the diagonal).  RCCL chooses its transport itself. */
+int32_t epi_grid_multi_peer_access(const epi_grid_multi *m, uint8_t *can_access);
+/* Test hook: the next epi_grid_multi_run fails with EPI_ERR_DEVICE when it reaches share `share`'s enqueue, after
+ * the shares before it have been enqueued (-1 disarms).  One shot. */
+int32_t epi_grid_multi_inject_failure(epi_grid_multi *m, int32_t share);
 int32_t epi_grid_multi_destroy(epi_grid_multi *m);
 /* create + run + destroy. */
 int32_t epi_calibrate_grid_multi(const epi_grid_desc *desc, const int32_t *devices, int32_t n_dev, double *loss,

@@ -78,3 +78,58 @@ def test_multi_full_size_c2(epi):
     m.close()
     np.testing.assert_array_equal(out["loss"], whole["loss"])
     assert (out["best_idx"], out["best_loss"]) == epi.grid_argmin(whole["loss"])
+
+
+def test_a_share_that_fails_at_enqueue_leaves_a_reusable_handle(epi):
+    """Share 2 of 3 fails on the host after shares 0 and 1 were enqueued: the call must wait for those two, collect
+    their status, name the failing share -- and the very next run must give the whole surface again."""
+    from epidemicsimulator_amd import synth, _capi
+    wl = synth.small_workload(40, 5, 7, 130, seed=21)
+    eng = epi.GridEngine(*_args(epi, wl, 130))
+    whole = eng.run()
+    eng.close()
+    m = epi.MultiGridEngine(*_args(epi, wl, 130), devices=[0, 0, 0])
+    for share in (2, 0, 1):
+        m.inject_failure(share)
+        with pytest.raises(epi.EpiError) as ei:
+            m.run()
+        assert ei.value.status == _capi.EPI_ERR_DEVICE and "share %d" % share in ei.value.message, ei.value.message
+        out = m.run()
+        np.testing.assert_array_equal(out["loss"], whole["loss"])
+        np.testing.assert_array_equal(out["arrival"], whole["arrival"])
+    m.close()
+
+
+def test_a_share_that_fails_on_the_device_is_reported_and_the_handle_survives(epi):
+    """The Int-range world: every episode overflows on the device.  Each run reports it with a clean status (never
+    a stale 'earlier run' failure, never a hang), twice in a row, and destroy works."""
+    from epidemicsimulator_amd import synth
+    countries, xy = synth.make_countries(3, 1)
+    for c, p in zip(countries, (2_000_000_000, 2_000_000_000, 100_000_000)):
+        c.pop = p
+    W = np.array([[0, 0, 0.2], [0, 0, 0.2], [0, 0, 0]], dtype=np.float64)
+    wl = synth.small_workload(3, 2, 3, 8, seed=1)
+    wl["countries"], wl["profiles"], wl["conn"] = countries, countries, W
+    m = epi.MultiGridEngine(*_args(epi, wl, 8), devices=[0, 0, 0, 0])
+    for _ in range(2):
+        with pytest.raises(epi.EpiError) as ei:
+            m.run()
+        assert ei.value.status in (3, 4, 6), ei.value
+        assert "instance 0," in ei.value.message, ei.value.message     # the first failing share's first grid point
+    m.close()
+
+
+def test_multi_timing_and_peer_table(epi):
+    from epidemicsimulator_amd import synth
+    wl = synth.small_workload(70, 4, 4, 60, seed=5)
+    m = epi.MultiGridEngine(*_args(epi, wl, 60), devices=[0, 0])
+    m.run(want_metrics=False)
+    m.set_timing(True)
+    for _ in range(3):
+        m.run(want_metrics=False)
+    t = m.times()
+    assert t["runs"] == 3 and len(t["share_kernel_ms"]) == 2
+    assert all(x > 0 for x in t["share_kernel_ms"]) and t["gather_ms"] > 0
+    assert t["wall_ms"] >= max(t["share_kernel_ms"]) * 0.5
+    assert m.peer_access().tolist() == [[1]]
+    m.close()
