@@ -596,15 +596,16 @@ def test_grid_full_size_properties(epi):
         np.testing.assert_array_equal(one["arrival"][0], out["arrival"][g])
         np.testing.assert_array_equal(one["peak"][0], out["peak"][g])
     eng.close()
-    # two grid points of the full-size configuration against the oracle
-    wl2 = dict(wl); wl2["betas"], wl2["travel"] = [wl["betas"][5]], [wl["travel"][3], wl["travel"][30]]
-    want = util.oracle_grid(wl2, base)
-    got = dict(loss=out["loss"][[5 * 32 + 3, 5 * 32 + 30]], arrival=out["arrival"][[5 * 32 + 3, 5 * 32 + 30]],
-               peak=out["peak"][[5 * 32 + 3, 5 * 32 + 30]])
-    assert want["err"] == 0
-    np.testing.assert_array_equal(got["arrival"], want["arrival"])
-    np.testing.assert_array_equal(got["peak"], want["peak"])
-    np.testing.assert_allclose(got["loss"], want["loss"], rtol=1e-12, atol=0)
+    # 32 grid points of the full-size configuration against the oracle: four beta rows (first and last among them) x
+    # eight travel scales -- first, last, and scales on either side of the point (row sum x ts = 0.2) where the cap of
+    # ToyConn.scaleRow starts to change the seed row (ToyConn.scala:63-66)
+    pts = [(b, t) for b in (0, 5, 19, 31) for t in (0, 3, 11, 22, 24, 27, 30, 31)]
+    assert not util.seed_row_cap_binds(wl, 22) and util.seed_row_cap_binds(wl, 27) and util.seed_row_cap_binds(wl, 31)
+    want = util.oracle_points(wl, base, pts)
+    flat = [b * 32 + t for b, t in pts]
+    np.testing.assert_array_equal(out["arrival"][flat], want["arrival"])
+    np.testing.assert_array_equal(out["peak"][flat], want["peak"])
+    np.testing.assert_allclose(out["loss"][flat], want["loss"], rtol=1e-12, atol=0)
 
 
 def test_grid_full_size_c3(epi):
@@ -624,15 +625,20 @@ def test_grid_full_size_c3(epi):
     np.testing.assert_array_equal(slab["loss"], out["loss"][g0:g0 + cnt])
     assert (slab["arrival"] >= 0).all() and (slab["arrival"] <= wl["steps"]).all() and (slab["arrival"][:, 0] == 0).all()
     eng.close()
-    g = 37 * 64 + 11
-    wl1 = dict(wl); wl1["betas"], wl1["travel"] = [wl["betas"][37]], [wl["travel"][11]]
-    want = util.oracle_grid(wl1, base)
-    assert want["err"] == 0
-    got = util.engine_grid(wl1, base)
-    np.testing.assert_array_equal(got["arrival"], want["arrival"])
-    np.testing.assert_array_equal(got["peak"], want["peak"])
-    np.testing.assert_allclose(got["loss"], want["loss"], rtol=1e-12, atol=0)
-    assert got["loss"][0] == out["loss"][g]
+    # 16 grid points against the oracle (one thread each): beta rows 0, 21, 37, 63 x travel scales first / one
+    # below and one above the point where ToyConn.scaleRow's 0.2 row-sum cap binds (ToyConn.scala:63-66) / last
+    pts = [(b, t) for b in (0, 21, 37, 63) for t in (0, 50, 56, 63)]
+    assert not util.seed_row_cap_binds(wl, 50) and util.seed_row_cap_binds(wl, 56) and util.seed_row_cap_binds(wl, 63)
+    want = util.oracle_points(wl, base, pts)
+    eng = epi.GridEngine(epi.HyperParams(), wl["steps"], base, 0, [c.pop for c in wl["countries"]], wl["conn"],
+                         wl["profiles"], wl["betas"], wl["travel"], wl["t_arrive"], wl["t_peak"], True)
+    for k, (b, t) in enumerate(pts):
+        got = eng.run(b * 64 + t, 1)
+        np.testing.assert_array_equal(got["arrival"][0], want["arrival"][k])
+        np.testing.assert_array_equal(got["peak"][0], want["peak"][k])
+        np.testing.assert_allclose(got["loss"][0], want["loss"][k], rtol=1e-12, atol=0)
+        assert got["loss"][0] == out["loss"][b * 64 + t]
+    eng.close()
 
 
 def test_grid_full_size_c4(epi):
@@ -655,15 +661,29 @@ def test_grid_full_size_c4(epi):
         np.testing.assert_array_equal(one["peak"][0], out["peak"][g])
     eng.close()
     # three grid points (first, middle, last beta row; different travel scales) for all 200 steps against the oracle's CSR world
-    for bi, ti in ((0, 3), (9, 4), (15, 15)):
-        wl2 = dict(wl)
-        wl2["betas"], wl2["travel"] = [wl["betas"][bi]], [wl["travel"][ti]]
-        want = util.oracle_grid(wl2, base, sparse=True)
-        assert want["err"] == 0
-        g = bi * 16 + ti
-        np.testing.assert_array_equal(out["arrival"][g], want["arrival"][0])
-        np.testing.assert_array_equal(out["peak"][g], want["peak"][0])
-        np.testing.assert_allclose(out["loss"][g], want["loss"][0], rtol=1e-12, atol=0)
+    pts = [(0, 3), (9, 4), (15, 15)]
+    want = util.oracle_points(wl, base, pts, sparse=True)
+    flat = [b * 16 + t for b, t in pts]
+    np.testing.assert_array_equal(out["arrival"][flat], want["arrival"])
+    np.testing.assert_array_equal(out["peak"][flat], want["peak"])
+    np.testing.assert_allclose(out["loss"][flat], want["loss"], rtol=1e-12, atol=0)
+    # and one sweep seeded in the graph's longest row (more than 32 stored weights: a row the lane-per-row blocks do
+    # not hold, so its travel-scale variants take the one-wave-per-row path), two travel scales, cap binding in one
+    rp = wl["conn"][0]
+    deg = np.diff(rp)
+    hub = int(np.argmax(deg))
+    assert deg[hub] > 32, "the 20,000-patch graph has a row beyond the 32 lane slots"
+    wl3 = dict(wl, seed_idx=hub)
+    pts3 = [(4, 2), (11, 14)]
+    want3 = util.oracle_points(wl3, base, pts3, sparse=True)
+    eng3 = epi.GridEngine(epi.HyperParams(), wl["steps"], base, hub, [c.pop for c in wl["countries"]], wl["conn"],
+                          wl["profiles"], wl["betas"], wl["travel"], wl["t_arrive"], wl["t_peak"], True)
+    for k, (b, t) in enumerate(pts3):
+        got = eng3.run(b * 16 + t, 1)
+        np.testing.assert_array_equal(got["arrival"][0], want3["arrival"][k])
+        np.testing.assert_array_equal(got["peak"][0], want3["peak"][k])
+        np.testing.assert_allclose(got["loss"][0], want3["loss"][k], rtol=1e-12, atol=0)
+    eng3.close()
 
 
 # ---------------------------------------------------------------- sparse (CSR) worlds, n > 1024

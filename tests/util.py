@@ -31,6 +31,40 @@ def oracle_grid(wl, base, heterogeneous=True, sparse=False):
                           heterogeneous)
 
 
+def oracle_points(wl, base, points, threads=16, sparse=False, heterogeneous=True):
+    """Oracle results of the grid points `points` = [(i_beta, i_travel), ...] of a workload, one single-point sweep
+    per point, `threads` of them at a time (the C oracle releases the interpreter lock): dict(loss[P], arrival[P][n],
+    peak[P][n])."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(pt):
+        w = dict(wl)
+        w["betas"], w["travel"] = [wl["betas"][pt[0]]], [wl["travel"][pt[1]]]
+        out = oracle_grid(w, base, heterogeneous, sparse)
+        assert out["err"] == 0, (pt, out["err"])
+        return out
+
+    with ThreadPoolExecutor(max_workers=max(1, min(threads, len(points)))) as ex:
+        outs = list(ex.map(one, points))
+    return dict(loss=np.array([o["loss"][0] for o in outs]), arrival=np.stack([o["arrival"][0] for o in outs]),
+                peak=np.stack([o["peak"][0] for o in outs]))
+
+
+def seed_row_cap_binds(wl, i_travel, cap=0.2):
+    """Whether ToyConn.scaleRow's row-sum cap (ToyConn.scala:63-66) changes the seed row at this travel scale."""
+    n = len(wl["countries"])
+    i = wl["seed_idx"]
+    if isinstance(wl["conn"], tuple):
+        rp, col, val = wl["conn"]
+        row = [v for c, v in zip(col[rp[i]:rp[i + 1]], val[rp[i]:rp[i + 1]]) if c != i]
+    else:
+        row = [wl["conn"][i][j] for j in range(n) if j != i]
+    s = 0.0
+    for v in row:
+        s += v * wl["travel"][i_travel]
+    return s > cap
+
+
 def dense_of(conn, n):
     if isinstance(conn, tuple):
         rp, col, val = conn
