@@ -596,10 +596,10 @@ def test_grid_full_size_properties(epi):
         np.testing.assert_array_equal(one["arrival"][0], out["arrival"][g])
         np.testing.assert_array_equal(one["peak"][0], out["peak"][g])
     eng.close()
-    # 32 grid points of the full-size configuration against the oracle: four beta rows (first and last among them) x
+    # 48 grid points of the full-size configuration against the oracle: six beta rows (first and last among them) x
     # eight travel scales -- first, last, and scales on either side of the point (row sum x ts = 0.2) where the cap of
     # ToyConn.scaleRow starts to change the seed row (ToyConn.scala:63-66)
-    pts = [(b, t) for b in (0, 5, 19, 31) for t in (0, 3, 11, 22, 24, 27, 30, 31)]
+    pts = [(b, t) for b in (0, 5, 12, 19, 26, 31) for t in (0, 3, 11, 22, 24, 27, 30, 31)]
     assert not util.seed_row_cap_binds(wl, 22) and util.seed_row_cap_binds(wl, 27) and util.seed_row_cap_binds(wl, 31)
     want = util.oracle_points(wl, base, pts)
     flat = [b * 32 + t for b, t in pts]
@@ -625,9 +625,9 @@ def test_grid_full_size_c3(epi):
     np.testing.assert_array_equal(slab["loss"], out["loss"][g0:g0 + cnt])
     assert (slab["arrival"] >= 0).all() and (slab["arrival"] <= wl["steps"]).all() and (slab["arrival"][:, 0] == 0).all()
     eng.close()
-    # 16 grid points against the oracle (one thread each): beta rows 0, 21, 37, 63 x travel scales first / one
+    # 32 grid points against the oracle (sixteen at a time, one thread each): eight beta rows, first and last among them, x travel scales first / one
     # below and one above the point where ToyConn.scaleRow's 0.2 row-sum cap binds (ToyConn.scala:63-66) / last
-    pts = [(b, t) for b in (0, 21, 37, 63) for t in (0, 50, 56, 63)]
+    pts = [(b, t) for b in (0, 9, 21, 30, 37, 46, 55, 63) for t in (0, 50, 56, 63)]
     assert not util.seed_row_cap_binds(wl, 50) and util.seed_row_cap_binds(wl, 56) and util.seed_row_cap_binds(wl, 63)
     want = util.oracle_points(wl, base, pts)
     eng = epi.GridEngine(epi.HyperParams(), wl["steps"], base, 0, [c.pop for c in wl["countries"]], wl["conn"],
