@@ -990,8 +990,10 @@ class WorldToy:
 # ------------------------------------------------------------------------------------------------
 # Calibrate.scala
 # ------------------------------------------------------------------------------------------------
-def _grid_desc(hp, steps, base, seed_idx, pops, conn, profiles, betas, travel, t_arrive, t_peak, heterogeneous, device):
-    """Fills an epi_grid_desc; returns it with the arrays it points into (keep them alive while it is used)."""
+def _grid_desc(hp, steps, base, seed_idx, pops, conn, profiles, betas, travel, t_arrive, t_peak, heterogeneous, device,
+               names=None):
+    """Fills an epi_grid_desc; returns it with the arrays it points into (keep them alive while it is used).
+    `names` (country names) decide the learningIntensity of WorldToy.scala:157-162 for rollouts that learn."""
     n = len(pops)
     pops = i32(pops)
     dense, rp, col, val = _csr_or_dense(conn)
@@ -1012,19 +1014,24 @@ def _grid_desc(hp, steps, base, seed_idx, pops, conn, profiles, betas, travel, t
     d.n_beta, d.betas, d.n_travel, d.travel = len(betas), ptr(betas, C.c_double), len(travel), ptr(travel, C.c_double)
     d.t_arrive, d.has_arrive, d.t_peak, d.has_peak = ptr(ta, C.c_double), ptr(ha, C.c_uint8), ptr(tp, C.c_double), ptr(hk, C.c_uint8)
     d.device = device
-    return d, (pops, dense, rp, col, val, prof_arr, ta, tp, ha, hk, betas, travel)
+    # rollouts long enough for their agents to learn (WorldToy.scala:147-167)
+    intensity = i32([WorldToy.LEARNING_INTENSITY.get(nm, 1) for nm in names] if names is not None else [1] * n)
+    learn = _capi.LearnHyper(hp.gamma, hp.lr, hp.clip_q, hp.grad_clip, hp.ema_alpha, hp.hidden, hp.replay_capacity,
+                             hp.target_update_every, hp.batch_size * int(max(intensity.max(), 1)))
+    d.learn, d.learn_intensity = C.pointer(learn), ptr(intensity, C.c_int32)
+    return d, (pops, dense, rp, col, val, prof_arr, ta, tp, ha, hk, betas, travel, learn, intensity)
 
 
 class GridEngine:
     """Device-resident calibration sweep (epi_grid_*): build once, run slabs of grid points."""
 
     def __init__(self, hp: HyperParams, steps: int, base: State, seed_idx: int, pops, conn, profiles, betas, travel,
-                 t_arrive=None, t_peak=None, heterogeneous=True, device: int = 0):
+                 t_arrive=None, t_peak=None, heterogeneous=True, device: int = 0, names: Optional[Sequence[str]] = None):
         self.n = len(pops)
         self.betas, self.travel = f64(betas), f64(travel)
         self.G = len(self.betas) * len(self.travel)
         d, _keep = _grid_desc(hp, steps, base, seed_idx, pops, conn, profiles, self.betas, self.travel, t_arrive, t_peak,
-                              heterogeneous, device)
+                              heterogeneous, device, names)
         h = lib().epi_grid_create(C.byref(d))
         if not h:
             _capi.raise_last()
@@ -1091,12 +1098,13 @@ class MultiGridEngine:
     devices[k]; the loss pieces are all-gathered with RCCL; run() returns the whole surface and its first minimum."""
 
     def __init__(self, hp: HyperParams, steps: int, base: State, seed_idx: int, pops, conn, profiles, betas, travel,
-                 t_arrive=None, t_peak=None, heterogeneous=True, devices: Sequence[int] = (0,)):
+                 t_arrive=None, t_peak=None, heterogeneous=True, devices: Sequence[int] = (0,),
+                 names: Optional[Sequence[str]] = None):
         self.n = len(pops)
         self.betas, self.travel = f64(betas), f64(travel)
         self.G = len(self.betas) * len(self.travel)
         d, _keep = _grid_desc(hp, steps, base, seed_idx, pops, conn, profiles, self.betas, self.travel, t_arrive, t_peak,
-                              heterogeneous, 0)
+                              heterogeneous, 0, names)
         dev = i32(list(devices))
         self.n_shares = len(dev)
         h = lib().epi_grid_multi_create(C.byref(d), ptr(dev, C.c_int32), C.c_int32(len(dev)))
@@ -1182,10 +1190,10 @@ class Calibrate:
             return [], (1.7976931348623157e308, best)
         if devices is not None:   # several GPUs of the node from this process, loss pieces all-gathered with RCCL
             eng = MultiGridEngine(hp, cfg.steps_per_epoch, base, seed_idx, [c.pop for c in countries], conn, profiles,
-                                  beta_grid, travel_scales, ta, tp, heterogeneous, devices)
+                                  beta_grid, travel_scales, ta, tp, heterogeneous, devices, names=names)
         else:
             eng = GridEngine(hp, cfg.steps_per_epoch, base, seed_idx, [c.pop for c in countries], conn, profiles,
-                             beta_grid, travel_scales, ta, tp, heterogeneous, device)
+                             beta_grid, travel_scales, ta, tp, heterogeneous, device, names=names)
         try:
             out = eng.run(want_metrics=False)
         finally:

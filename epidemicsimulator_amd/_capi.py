@@ -53,15 +53,15 @@ class CHyper(C.Structure):
                 ("batch_size", C.c_int32), ("learn_every", C.c_int32)]
 
 
+_PD = C.POINTER(C.c_double)
+_PI = C.POINTER(C.c_int32)
+_PU8 = C.POINTER(C.c_uint8)
+
+
 class LearnHyper(C.Structure):
     _fields_ = [("gamma", C.c_double), ("lr", C.c_double), ("clip_q", C.c_double), ("grad_clip", C.c_double),
                 ("ema_alpha", C.c_double), ("hidden", C.c_int32), ("replay_capacity", C.c_int32),
                 ("target_update_every", C.c_int32), ("max_need", C.c_int32)]
-
-
-_PD = C.POINTER(C.c_double)
-_PI = C.POINTER(C.c_int32)
-_PU8 = C.POINTER(C.c_uint8)
 
 
 class GridDesc(C.Structure):
@@ -69,7 +69,8 @@ class GridDesc(C.Structure):
                 ("csr_val", _PD), ("seed_idx", C.c_int32), ("heterogeneous", C.c_int32), ("base", CState),
                 ("prof", C.POINTER(Profile)), ("hp", CHyper), ("steps", C.c_int32), ("n_beta", C.c_int32),
                 ("betas", _PD), ("n_travel", C.c_int32), ("travel", _PD), ("t_arrive", _PD), ("has_arrive", _PU8),
-                ("t_peak", _PD), ("has_peak", _PU8), ("device", C.c_int32), ("pad_", C.c_int32)]
+                ("t_peak", _PD), ("has_peak", _PU8), ("device", C.c_int32), ("pad_", C.c_int32),
+                ("learn", C.POINTER(LearnHyper)), ("learn_intensity", _PI)]
 
 
 class WorldDesc(C.Structure):

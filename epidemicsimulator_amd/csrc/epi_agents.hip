@@ -670,6 +670,31 @@ EPI_API int32_t epi_agents_observe_world(epi_agents* g, epi_world* w) {
     return EPI_OK;
 }
 
+// The same filing for a calibration sweep whose rollouts learn: every (episode, country) pair of the view is a node of
+// its own world with its own agent (Calibrate.scala:56-65 builds a fresh WorldToy per grid point), so instance e's
+// country c files into agent e * v.n + c.
+namespace epi {
+int32_t agents_observe_instances(epi_agents* g, const WorldTransitionView& v) {
+    if (!g) return fail(EPI_ERR_BAD_ARGUMENT, "agents_observe_instances: null handle");
+    if (v.device != g->device) return fail(EPI_ERR_BAD_ARGUMENT, "agents_observe_instances: planes on device %d, agents on device %d", v.device, g->device);
+    if ((long long)v.n * v.batch != g->n) return fail(EPI_ERR_BAD_ARGUMENT, "agents_observe_instances: %d x %d transitions for %d agents", v.batch, v.n, g->n);
+    if (int32_t rc = use_device(g->device)) return rc;
+    const size_t count = (size_t)v.n * v.batch;
+    HIP_TRY(g->file_dst.ensure(count * sizeof(long long)));
+    long long* dst = g->file_dst.as<long long>();
+    for (int c = 0; c < v.n; ++c)
+        for (int e = 0; e < v.batch; ++e) {
+            const size_t agent = (size_t)e * v.n + c;
+            dst[(size_t)c * v.batch + e] = g->h_ring_off[agent] + g->replay[agent].push();
+        }
+    hipLaunchKernelGGL(agents_file_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, g->stream, g->ring.as<RingRec>(),
+                       g->file_dst.on_device<long long>(), v);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g->stream));  // the staging array is free again
+    return EPI_OK;
+}
+}  // namespace epi
+
 EPI_API int32_t epi_agents_replay_size(epi_agents* g, int32_t* sizes) {
     if (!g || !sizes) return fail(EPI_ERR_BAD_ARGUMENT, "agents_replay_size: null argument");
     for (int k = 0; k < g->n; ++k) sizes[k] = g->replay[k].size;

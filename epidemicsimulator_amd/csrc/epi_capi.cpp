@@ -565,6 +565,13 @@ struct epi_grid {
     // episodes one such call can take), so another handle's later call cannot overwrite what status() will read
     DevBuf noalloc_err;
     int noalloc_max_episodes = 0;
+    // rollouts whose agents learn before an argmax-Q step (WorldToy.scala:147-167): one agent per (episode, country)
+    bool learning = false;
+    epi_hyper hyper{};
+    epi_learn_hyper learn_hp{};
+    std::vector<int32_t> intensity;      // [n] gradAccumSteps of each country's learn call
+    DevBuf rwd;                          // [npad] RewardConsts (the agents observe the reward, WorldToy.scala:99)
+    DevBuf prev_st, prev_cap, prev_tcur, loc_s, loc_i, reward_dev, net_index;
 };
 
 struct epi_world {
@@ -853,6 +860,7 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
     G->device = d->device;
     G->n = d->n; G->steps = d->steps; G->n_beta = d->n_beta; G->n_travel = d->n_travel; G->seed_idx = d->seed_idx;
     G->base = d->base;
+    G->hyper = d->hp;
     // a sparse graph is renumbered inside the engine (GraphTables::renumbered): every per-country table below is
     // filed under in(c), and the loss kernel reads arrival / peak back through the same map
     rc = G->graph.build(d->n, d->pop, d->conn, d->csr_rowptr, d->csr_col, d->csr_val, true);
@@ -997,15 +1005,44 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
         }
         HIP_TRY(G->actions.upload(ha));
         // WorldToy.stepOne lets every agent learn once gStep >= learnEvery and its replay buffer holds 4 * batchSize
-        // transitions (WorldToy.scala:150-167; one transition per step, :99).  The sweep runs untrained networks
-        // only: an argmax-Q step at or after that point would consult weights this engine has not trained.
+        // transitions (WorldToy.scala:150-167; one transition per step, :99).  An argmax-Q step at or after that point
+        // consults trained weights: such a sweep runs with one learning agent per (episode, country), step by step.
         const long long learn_from = std::max<long long>(1, std::max<long long>(hp.learn_every, 4LL * hp.batch_size));
+        const bool ever_learns = !d->learn || (long long)d->learn->replay_capacity >= 4LL * hp.batch_size;   // a smaller buffer never fills
+        int first_trained = -1;
         for (int gs : G->greedy_steps)
-            if (gs >= learn_from)
+            if (gs >= learn_from && ever_learns) { first_trained = gs; break; }
+        if (first_trained >= 0) {
+            if (!d->learn)
                 return fail(EPI_ERR_UNSUPPORTED,
                             "grid: the agents start learning after step %lld (learnEvery %d, batchSize %d) and step %d takes argmax Q: "
-                            "rollouts that consult trained weights are not part of the sweep engine",
-                            learn_from, hp.learn_every, hp.batch_size, gs);
+                            "rollouts that consult trained weights need epi_grid_desc.learn (the HyperParams of DDQNAgent.learn)",
+                            learn_from, hp.learn_every, hp.batch_size, first_trained);
+            if (G->graph.sparse)
+                return fail(EPI_ERR_UNSUPPORTED, "grid: rollouts whose agents learn (from step %lld on) are run for dense worlds of at most "
+                                                 "1,024 countries; this one has %d patches", learn_from, n);
+            if (d->learn->hidden != hp.hidden)
+                return fail(EPI_ERR_BAD_ARGUMENT, "grid: learn->hidden = %d but hp.hidden = %d (one HyperParams record, config.scala:13)",
+                            d->learn->hidden, hp.hidden);
+            if (d->learn->replay_capacity <= 0 || d->learn->target_update_every <= 0 || hp.batch_size <= 0 || hp.learn_every < 0)
+                return fail(EPI_ERR_BAD_ARGUMENT, "grid: learn: replay_capacity, target_update_every and batch_size must be positive");
+            G->learning = true;
+            G->learn_hp = *d->learn;
+            G->intensity.assign((size_t)n, 1);
+            for (int c = 0; c < n && d->learn_intensity; ++c) {
+                if (d->learn_intensity[c] < 1) return fail(EPI_ERR_BAD_ARGUMENT, "grid: learn_intensity[%d] = %d", c, d->learn_intensity[c]);
+                G->intensity[(size_t)c] = d->learn_intensity[c];
+            }
+            std::vector<RewardConsts> hr((size_t)npad);
+            std::memset(hr.data(), 0, hr.size() * sizeof(RewardConsts));
+            for (int c = 0; c < n; ++c) {
+                epi_env_params e{};
+                e.reward_clip = hp.reward_clip;   // Calibrate.scala:32,47; riskFactor keeps its default 0.0
+                e.risk_factor = 0.0;
+                hr[(size_t)c] = make_reward_consts(e, d->heterogeneous ? d->prof[c] : kDefaultProfile);
+            }
+            HIP_TRY(G->rwd.upload(hr));
+        }
     }
     stamp("noise and actions");
     if (!G->greedy_steps.empty()) {
@@ -1150,6 +1187,119 @@ EPI_API int32_t epi_grid_run(epi_grid* g, int32_t g_begin, int32_t g_count, doub
     return epi_grid_run_strided(g, g_begin, 1, g_count, loss, arrival, peak, out_on_device, stream);
 }
 
+// The episodes of a sweep whose agents learn before an argmax-Q step (WorldToy.stepOne as Calibrate.rollout calls it,
+// Calibrate.scala:69-73): every (episode, country) pair is a node with a DDQNAgent of its own (WorldToy.scala:46-65), so
+// the episodes advance one step per launch and after every step the agents observe their transition (:99) and learn
+// when their schedule says so (:147-167).  All agents share HyperParams and the action stream's seed
+// (DDQNAgent.scala:14), so they explore on the same steps and, when they do, draw the same action; on an argmax-Q
+// step each asks its own online network.  Blocking: replay sampling is host work (ReplayBuffer.scala:21-22).
+static int32_t grid_run_learning(epi_grid* g, EpisodeArgs ea, const WorkPtrs& wp, hipStream_t s) {
+    const int n = g->n, npad = g->npad, count = ea.count;
+    const size_t cells = (size_t)count * npad;
+    const long long n_agents = (long long)count * n;
+    if (n_agents > 16384)
+        return fail(EPI_ERR_UNSUPPORTED, "grid: %d episodes x %d countries = %lld learning agents in one call, at most 16384: run fewer grid "
+                                         "points per call", count, n, n_agents);
+    const Hyper hp = to_hyper(g->hyper);
+    int max_intensity = 1;
+    for (int v : g->intensity) max_intensity = std::max(max_intensity, v);
+    epi_learn_hyper lh = g->learn_hp;
+    lh.max_need = hp.batch_size * max_intensity;          // DDQNAgent.scala:52
+    // a buffer that can hold every transition of the rollout never wraps: no need to allocate beyond the rollout's length
+    lh.replay_capacity = std::min(lh.replay_capacity, std::max(1, g->steps));
+    std::vector<epi_learn_hyper> lhs((size_t)n_agents, lh);
+    struct AgentsOwner {
+        epi_agents* p = nullptr;
+        ~AgentsOwner() { if (p) epi_agents_destroy(p); }
+    } agents;
+    agents.p = epi_agents_create((int32_t)n_agents, lhs.data(), g->device);
+    if (!agents.p) return g_last_code ? g_last_code : EPI_ERR_DEVICE;
+    AgentsNetView view{};
+    if (int32_t rc = agents_net_view(agents.p, &view)) return rc;
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(g->prev_st.ensure(cells * 5 * sizeof(int32_t)));
+    HIP_TRY(g->prev_cap.ensure(cells * sizeof(double)));
+    HIP_TRY(g->prev_tcur.ensure(cells * sizeof(int32_t)));
+    HIP_TRY(g->loc_s.ensure(cells * sizeof(int32_t)));
+    HIP_TRY(g->loc_i.ensure(cells * sizeof(int32_t)));
+    HIP_TRY(g->reward_dev.ensure(cells * sizeof(double)));
+    {   // network of every (episode, padded country) cell: agent e * n + c; padding columns are evaluated and ignored
+        std::vector<int32_t> ni(cells, 0);
+        for (int e = 0; e < count; ++e)
+            for (int c = 0; c < n; ++c) ni[(size_t)e * npad + c] = e * n + c;
+        HIP_TRY(g->net_index.upload(ni));
+    }
+    ea.rwd = g->rwd.as<RewardConsts>();
+    ea.reward_out = g->reward_dev.as<double>();
+    ea.loc_s = g->loc_s.as<int32_t>(); ea.loc_i = g->loc_i.as<int32_t>();
+    ea.act_episode = wp.act_ep;
+
+    WorldTransitionView tv{};
+    tv.device = g->device; tv.n = n; tv.npad = npad; tv.batch = count; tv.t_max = g->base.t_max;
+    tv.plane = cells;
+    tv.prev_st = g->prev_st.as<int32_t>(); tv.prev_cap = g->prev_cap.as<double>(); tv.prev_tcur = g->prev_tcur.as<int32_t>();
+    tv.loc_s = g->loc_s.as<int32_t>(); tv.loc_i = g->loc_i.as<int32_t>();
+    tv.st = wp.st; tv.cap = wp.cap; tv.reward = g->reward_dev.as<double>(); tv.act = wp.act_ep;
+
+    std::vector<int8_t> shared_actions((size_t)std::max(1, g->steps));
+    {
+        AgentStream ag;   // the same stream the action table was built from (DDQNAgent.scala:14,26-32)
+        for (int t = 0; t < g->steps; ++t) shared_actions[(size_t)t] = (int8_t)ag.act(hp);
+    }
+    std::vector<int32_t> batch((size_t)n_agents, hp.batch_size), accum((size_t)n_agents), sizes((size_t)n_agents);
+    for (long long k = 0; k < n_agents; ++k) accum[(size_t)k] = g->intensity[(size_t)(k % n)];
+    std::vector<int64_t> act_calls((size_t)n_agents);
+    std::vector<double> losses((size_t)n_agents);
+    long long g_step = 0, last_learn = 0;   // every node of every episode is on the same schedule (one HyperParams record)
+    const int rows_per_launch = std::max(1, 65535 / npad);   // grid.y of the network kernel
+
+    for (int t = 0; t < g->steps; ++t) {
+        // Transition.s (WorldToy.scala:99): the states as they are before this step
+        HIP_TRY(hipMemcpyAsync(g->prev_st.p, wp.st, cells * 5 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(g->prev_cap.p, wp.cap, cells * sizeof(double), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(g->prev_tcur.p, wp.tcur, cells * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        const int a = shared_actions[(size_t)t];
+        if (a == kGreedyAction) {
+            // DDQNAgent.actGreedy on each node's own online network: the cells of `rows_per_launch` episodes are handed
+            // to the network kernel as so many "countries" of one instance, each with its own network
+            for (int e0 = 0; e0 < count; e0 += rows_per_launch) {
+                const int m = std::min(rows_per_launch, count - e0);
+                const size_t off = (size_t)e0 * npad;
+                MlpArgs ma{};
+                ma.rows = m * npad; ma.n = m * npad; ma.npad = m * npad; ma.count = 1;
+                ma.state_t_max = g->base.t_max;
+                ma.st = wp.st + off; ma.cap = wp.cap + off; ma.tcur = wp.tcur + off; ma.plane = cells;
+                ma.nl = view.nl; ma.nets = view.nets; ma.net_stride = view.net_stride; ma.per_country = 1;
+                ma.net_index = g->net_index.as<int32_t>() + off;
+                ma.clip_ptr = view.clip_ptr; ma.clip_stride = view.clip_stride; ma.clip_q = 0.0;
+                ma.act_episode = wp.act_ep + off;
+                HIP_TRY(launch_mlp(ma, s));
+            }
+        } else {
+            HIP_TRY(hipMemsetAsync(wp.act_ep, a, cells, s));   // one byte per cell: the action everybody drew
+        }
+        ea.t_begin = t; ea.t_end = t + 1;
+        int32_t rc = timed_episode(g, ea, s);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(s));
+        rc = agents_observe_instances(agents.p, tv);   // agent.observe(Transition(s, a, r, s2, done)), WorldToy.scala:99
+        if (rc) return rc;
+        g_step += 1;
+        // WorldToy.scala:150-167
+        if (g_step - last_learn >= hp.learn_every) {
+            rc = epi_agents_replay_size(agents.p, sizes.data());
+            if (rc) return rc;
+            if ((long long)sizes[0] >= 4LL * hp.batch_size) {
+                std::fill(act_calls.begin(), act_calls.end(), (int64_t)(t + 1));   // DDQNAgent.steps: one act() per world step
+                rc = epi_agents_learn(agents.p, nullptr, (int32_t)n_agents, batch.data(), accum.data(), act_calls.data(), losses.data(), nullptr);
+                if (rc) return rc;
+                last_learn = g_step;
+            }
+        }
+    }
+    return EPI_OK;
+}
+
 // Enqueues init -> episode segments (split around the argmax-Q steps) -> loss for the given grid points on `s`,
 // with the per-episode state in `wp`.  Allocates nothing unless `may_allocate` and timing is on (HIP events per launch).
 static int32_t grid_enqueue(epi_grid* g, int32_t g_begin, int32_t g_stride, int32_t g_count, const WorkPtrs& wp, double* d_loss,
@@ -1202,8 +1352,16 @@ static int32_t grid_enqueue(epi_grid* g, int32_t g_begin, int32_t g_stride, int3
         return EPI_OK;
     };
 
-    int t0 = 0;
+    if (g->learning) {
+        if (!may_allocate)
+            return fail(EPI_ERR_UNSUPPORTED, "epi_grid_run_noalloc: this sweep's rollouts learn (one agent per grid point and country is "
+                                             "allocated per call): use epi_grid_run_strided");
+        rc = grid_run_learning(g, ea, wp, s);
+        if (rc) return rc;
+    }
+    int t0 = g->learning ? g->steps : 0;
     for (int gs : g->greedy_steps) {
+        if (g->learning) break;
         if (gs > t0) {
             ea.t_begin = t0; ea.t_end = gs; ea.act_episode = nullptr;
             rc = episode(ea);

@@ -273,6 +273,8 @@ struct AgentsNetView {
 struct epi_agents;
 namespace epi {
 int32_t agents_net_view(epi_agents* g, AgentsNetView* v);
+// Files the transitions of `v` with instance e's country c going to agent e * v.n + c (epi_agents.hip).
+int32_t agents_observe_instances(epi_agents* g, const WorldTransitionView& v);
 
 // The same matrix cut to a sparse graph on the device: entries W_ij > threshold (i != j), columns ascending.
 // mode 0: scale[i] = the row's cap factor min(1, cap_row / rowSum) (1 for an empty row); mode 1: counts[i] = stored

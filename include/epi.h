@@ -136,6 +136,15 @@ int32_t epi_mlp_greedy_batch(const epi_state *states, int32_t batch, int32_t hid
                              const double *b1, const double *W2, const double *b2, const double *W3,
                              const double *b3, double clip_q, double *q, int32_t *action);
 
+/* HyperParams fields the learn step reads (config.scala:3-21), one record per agent. */
+typedef struct epi_learn_hyper {
+    double gamma, lr, clip_q, grad_clip, ema_alpha;
+    int32_t hidden;              /* one width per handle */
+    int32_t replay_capacity;
+    int32_t target_update_every;
+    int32_t max_need;            /* largest batch * gradAccumSteps epi_agents_learn will be asked for */
+} epi_learn_hyper;
+
 /* ---- Calibrate.gridSurface / rollout (Calibrate.scala:19-116) over WorldToy.stepOne
  *      (WorldToy.scala:24-32,83-145), Validation.arrivalTime/peakI (Validation.scala:15-22) ------ */
 typedef struct epi_grid_desc {
@@ -161,6 +170,18 @@ typedef struct epi_grid_desc {
     const uint8_t *has_peak;
     int32_t device;         /* HIP device ordinal */
     int32_t pad_;
+    /* Learning inside a rollout.  Calibrate.rollout steps its world with WorldToy.stepOne, which lets every node's
+     * agent learn once gStep - lastLearnStep >= learnEvery and its replay buffer holds 4 * batchSize transitions
+     * (WorldToy.scala:147-167; one transition per step, :99).  A sweep whose episodes take an argmax-Q step after that
+     * point consults trained weights: it then runs one DDQNAgent per (grid point, country) on the device
+     * (DDQNAgent.scala:34-65, MLP.scala:29-99, ReplayBuffer.scala:10-22), step by step.  `learn` = the HyperParams
+     * fields the learn step reads (one record: Calibrate.scala:56-57 gives every agent the sweep's hp; hidden must
+     * equal hp.hidden; max_need is ignored); NULL = such a sweep is refused with EPI_ERR_UNSUPPORTED, as are sparse
+     * worlds and calls of more than 16,384 (grid point, country) pairs.  learn_intensity[n] = gradAccumSteps of each
+     * country's learn call (WorldToy.scala:157-162: 2 for "India", 1 otherwise); NULL = 1 everywhere.  Sweeps that
+     * never reach that point (the reference's defaults: 300 steps < 4 * 128) ignore both fields. */
+    const epi_learn_hyper *learn;
+    const int32_t *learn_intensity;
 } epi_grid_desc;
 
 typedef struct epi_grid epi_grid;
@@ -336,14 +357,7 @@ int32_t epi_world_destroy(epi_world *w);
 
 /* ---- DDQNAgent learning (DDQNAgent.scala:6-70) with MLP.trainBatch (MLP.scala:29-99) and
  *      ReplayBuffer (ReplayBuffer.scala:10-22): one agent per country (WorldToy.scala:46-65) ------ */
-/* HyperParams fields the learn step reads (config.scala:3-21), one record per agent. */
-typedef struct epi_learn_hyper {
-    double gamma, lr, clip_q, grad_clip, ema_alpha;
-    int32_t hidden;              /* one width per handle */
-    int32_t replay_capacity;
-    int32_t target_update_every;
-    int32_t max_need;            /* largest batch * gradAccumSteps epi_agents_learn will be asked for */
-} epi_learn_hyper;
+/* epi_learn_hyper (the HyperParams fields the learn step reads) is declared with the calibration sweep above. */
 
 /* n_agents fresh agents (two networks each from MLP.scala:5-9, empty replay buffers whose shuffle stream is
  * Random(123)) on `device`.  Returns NULL on failure. */

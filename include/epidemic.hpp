@@ -69,6 +69,10 @@ struct HyperParams {
     bool checkpoint = true;
     int learnEvery = 8;
     epi_hyper c() const { return epi_hyper{epsilonStart, epsilonEnd, epsilonDecaySteps, hidden, clipQ, rewardClip, batchSize, learnEvery}; }
+    // the fields DDQNAgent.learn reads (DDQNAgent.scala:51-65); maxNeed = the largest batch * gradAccumSteps asked for
+    epi_learn_hyper learn(int maxNeed) const {
+        return epi_learn_hyper{gamma, lr, clipQ, gradClip, emaAlpha, hidden, replayCapacity, targetUpdateEvery, maxNeed};
+    }
 };
 struct TrainConfig {
     int epochs = 1000, stepsPerEpoch = 500, evalEvery = 10;
@@ -725,6 +729,12 @@ inline Surface gridSurface(const HyperParams& hp, const TrainConfig& cfg, const 
     d.base = base.c(); d.prof = profs.data(); d.hp = hp.c(); d.steps = cfg.stepsPerEpoch;
     d.n_beta = (int)betaGrid.size(); d.betas = betaGrid.data(); d.n_travel = (int)travelScales.size(); d.travel = travelScales.data();
     d.t_arrive = ta.data(); d.has_arrive = ha.data(); d.t_peak = tp.data(); d.has_peak = hk.data(); d.device = 0;
+    // rollouts long enough for their agents to learn (WorldToy.scala:147-167): the learn step's hyper-parameters and
+    // the per-country learningIntensity of :157-162
+    const epi_learn_hyper lh = hp.learn(hp.batchSize * 2);
+    std::vector<int32_t> intensity;
+    for (int c = 0; c < n; ++c) intensity.push_back(countries[c].name == "India" ? 2 : 1);
+    d.learn = &lh; d.learn_intensity = intensity.data();
     std::vector<double> loss(betaGrid.size() * travelScales.size());
     int32_t bestIdx = 0;
     double bestLoss = 0;

@@ -877,6 +877,14 @@ EXPORT void orc_world_step(void *h, int32_t t_max, int32_t greedy, double *rewar
 /* ------------------------------------------------------------------------ */
 /* Calibrate -- Calibrate.scala:14-116                                       */
 /* ------------------------------------------------------------------------ */
+typedef struct {
+    double gamma, lr, clip_q, grad_clip, ema_alpha;
+    int32_t hidden, replay_capacity, target_update_every, max_need;
+} orc_learn_hyper;
+EXPORT void orc_world_enable_learning(void *h, const orc_learn_hyper *hp, const int32_t *learn_every,
+                                      const int32_t *batch_size, const int32_t *intensity);
+EXPORT void orc_world_step_learn(void *h, const orc_hyper *hps, int32_t t_max, double *rewards, double *losses);
+
 static double rmse(const double *x, int n) { /* :14-17 */
     double s = 0.0;
     for (int k = 0; k < n; k++) { double q = x[k] * x[k]; s = (k == 0) ? q : s + q; }
@@ -890,7 +898,7 @@ static void rollout_any(int32_t n, const int32_t *pop, const double *W, const in
                         const double *val, int32_t seed_idx, const orc_state *base,
                         const orc_profile *prof, const orc_hyper *hp, int32_t steps, double beta, double ts,
                         int32_t heterogeneous, int32_t *arrival, double *peak, double *final_i, double *series_out,
-                        int32_t *err) {
+                        int32_t *err, const orc_learn_hyper *lhp, const int32_t *intensity) {
     double *Ws = NULL, *vs = NULL;
     if (W) {
         Ws = (double *)malloc(sizeof(double) * (size_t)n * n);
@@ -934,10 +942,25 @@ static void rollout_any(int32_t n, const int32_t *pop, const double *W, const in
     world *w = W ? (world *)orc_world_create(n, pop, Ws, seed_idx, base, env, pr, seeds, hp, 1 /* validate = true :64 */)
                  : (world *)orc_world_create_csr(n, pop, rowptr, col, vs, seed_idx, base, env, pr, seeds, hp, 1);
     double *series = (double *)malloc(sizeof(double) * (size_t)n * (size_t)(steps > 0 ? steps : 1));
+    orc_hyper *hps = NULL;
+    if (lhp) {
+        /* the agents of the rollout's world learn as WorldToy.stepOne has them (WorldToy.scala:147-167): every node gets
+         * the sweep's HyperParams (Calibrate.scala:56-57 passes hp and no countryHyperParams) */
+        orc_learn_hyper *lh = (orc_learn_hyper *)malloc(sizeof(orc_learn_hyper) * (size_t)n);
+        int32_t *le = (int32_t *)malloc(4 * (size_t)n), *bs = (int32_t *)malloc(4 * (size_t)n), *it = (int32_t *)malloc(4 * (size_t)n);
+        hps = (orc_hyper *)malloc(sizeof(orc_hyper) * (size_t)n);
+        for (int c = 0; c < n; c++) {
+            lh[c] = *lhp; le[c] = hp->learn_every; bs[c] = hp->batch_size; it[c] = intensity ? intensity[c] : 1; hps[c] = *hp;
+        }
+        orc_world_enable_learning(w, lh, le, bs, it);
+        free(lh); free(le); free(bs); free(it);
+    }
     for (int t = 0; t < steps; t++) { /* :68-73 */
-        orc_world_step(w, steps, 0, NULL);
+        if (lhp) orc_world_step_learn(w, hps, steps, NULL, NULL);
+        else orc_world_step(w, steps, 0, NULL);
         for (int c = 0; c < n; c++) series[(size_t)c * steps + t] = w->cur[c].i;
     }
+    free(hps);
     for (int c = 0; c < n; c++) { /* :75-81 */
         const double *is = series + (size_t)c * steps;
         arrival[c] = orc_arrival_time(is, steps, 10.0);
@@ -957,7 +980,7 @@ EXPORT void orc_rollout(int32_t n, const int32_t *pop, const double *W, int32_t 
                         int32_t heterogeneous, int32_t *arrival, double *peak, double *final_i, double *series_out,
                         int32_t *err) {
     rollout_any(n, pop, W, NULL, NULL, NULL, seed_idx, base, prof, hp, steps, beta, ts, heterogeneous, arrival, peak, final_i,
-                series_out, err);
+                series_out, err, NULL, NULL);
 }
 
 /* Calibrate.gridSurface :84-116.  has_arr/has_pk are the Map key-presence masks.
@@ -969,7 +992,8 @@ static int32_t grid_surface_any(int32_t n, const int32_t *pop, const double *W, 
                                 int32_t steps, const double *betas, int32_t nb, const double *tss, int32_t nts,
                                 const double *t_arrive, const uint8_t *has_arr, const double *t_peak,
                                 const uint8_t *has_pk, int32_t heterogeneous, double *loss, int32_t *arrival_out,
-                                double *peak_out, int32_t *best_idx, double *best_loss) {
+                                double *peak_out, int32_t *best_idx, double *best_loss, const orc_learn_hyper *lhp,
+                                const int32_t *intensity) {
     int32_t *arr = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
     double *pk = (double *)malloc(sizeof(double) * (size_t)n);
     double *fin = (double *)malloc(sizeof(double) * (size_t)n);
@@ -979,7 +1003,8 @@ static int32_t grid_surface_any(int32_t n, const int32_t *pop, const double *W, 
     for (int b = 0; b < nb; b++)
         for (int k = 0; k < nts; k++) {
             int g = b * nts + k, err = 0;
-            rollout_any(n, pop, W, rowptr, col, val, seed_idx, base, prof, hp, steps, betas[b], tss[k], heterogeneous, arr, pk, fin, NULL, &err);
+            rollout_any(n, pop, W, rowptr, col, val, seed_idx, base, prof, hp, steps, betas[b], tss[k], heterogeneous, arr, pk, fin, NULL, &err,
+                        lhp, intensity);
             if (err && !first_err) first_err = err;
             for (int c = 0; c < n; c++) {
                 double a = (double)arr[c];
@@ -1006,7 +1031,21 @@ EXPORT int32_t orc_grid_surface(int32_t n, const int32_t *pop, const double *W, 
                                 const uint8_t *has_pk, int32_t heterogeneous, double *loss, int32_t *arrival_out,
                                 double *peak_out, int32_t *best_idx, double *best_loss) {
     return grid_surface_any(n, pop, W, NULL, NULL, NULL, seed_idx, base, prof, hp, steps, betas, nb, tss, nts, t_arrive, has_arr,
-                            t_peak, has_pk, heterogeneous, loss, arrival_out, peak_out, best_idx, best_loss);
+                            t_peak, has_pk, heterogeneous, loss, arrival_out, peak_out, best_idx, best_loss, NULL, NULL);
+}
+
+/* Calibrate.gridSurface with the rollouts' agents learning (WorldToy.stepOne as written, :147-167): what the reference
+ * does once a rollout is long enough for the replay buffers to hold 4 * batchSize transitions.  lhp = the
+ * HyperParams fields DDQNAgent.learn reads; intensity[c] = gradAccumSteps of country c's learn call (:157-162). */
+EXPORT int32_t orc_grid_surface_learn(int32_t n, const int32_t *pop, const double *W, int32_t seed_idx,
+                                      const orc_state *base, const orc_profile *prof, const orc_hyper *hp,
+                                      int32_t steps, const double *betas, int32_t nb, const double *tss, int32_t nts,
+                                      const double *t_arrive, const uint8_t *has_arr, const double *t_peak,
+                                      const uint8_t *has_pk, int32_t heterogeneous, double *loss, int32_t *arrival_out,
+                                      double *peak_out, int32_t *best_idx, double *best_loss, const orc_learn_hyper *lhp,
+                                      const int32_t *intensity) {
+    return grid_surface_any(n, pop, W, NULL, NULL, NULL, seed_idx, base, prof, hp, steps, betas, nb, tss, nts, t_arrive, has_arr,
+                            t_peak, has_pk, heterogeneous, loss, arrival_out, peak_out, best_idx, best_loss, lhp, intensity);
 }
 
 /* The same over a CSR graph: O(stored entries) per world step instead of O(n^2). */
@@ -1017,7 +1056,7 @@ EXPORT int32_t orc_grid_surface_csr(int32_t n, const int32_t *pop, const int32_t
                                     const uint8_t *has_pk, int32_t heterogeneous, double *loss, int32_t *arrival_out,
                                     double *peak_out, int32_t *best_idx, double *best_loss) {
     return grid_surface_any(n, pop, NULL, rowptr, col, val, seed_idx, base, prof, hp, steps, betas, nb, tss, nts, t_arrive, has_arr,
-                            t_peak, has_pk, heterogeneous, loss, arrival_out, peak_out, best_idx, best_loss);
+                            t_peak, has_pk, heterogeneous, loss, arrival_out, peak_out, best_idx, best_loss, NULL, NULL);
 }
 
 /* Timed leg for bench.py's cpu_baseline: runs `n_points` grid points starting at
@@ -1055,7 +1094,7 @@ EXPORT int64_t orc_bench_points_csr(int32_t n, const int32_t *pop, const int32_t
     for (int g = g0; g < g0 + n_points; g++) {
         int err = 0;
         rollout_any(n, pop, NULL, rowptr, col, val, seed_idx, base, prof, hp, steps, betas[g / nts], tss[g % nts], heterogeneous,
-                    arr, pk, fin, NULL, &err);
+                    arr, pk, fin, NULL, &err, NULL, NULL);
         for (int c = 0; c < n; c++) cs += pk[c] + (double)arr[c];
         done += (int64_t)n * steps;
     }
@@ -1073,10 +1112,6 @@ EXPORT int64_t orc_bench_points_csr(int32_t n, const int32_t *pop, const int32_t
 /* the Scala 2.13 library routine (a third-party dependency absent from the   */
 /* reference tree): copy, then for n = length down to 2 swap(n-1, nextInt(n)).*/
 /* ------------------------------------------------------------------------ */
-typedef struct {
-    double gamma, lr, clip_q, grad_clip, ema_alpha;
-    int32_t hidden, replay_capacity, target_update_every, max_need;
-} orc_learn_hyper;
 
 typedef struct {
     double fs[7], fs2[7], r;

@@ -358,6 +358,30 @@ def grid_surface(pops, W, seed_idx, base, profiles, steps, betas, tss, t_arrive,
     return dict(loss=loss, arrival=arr, peak=pk, best_idx=bi.value, best_loss=bl.value, err=err)
 
 
+def grid_surface_learn(pops, W, seed_idx, base, profiles, steps, betas, tss, t_arrive, has_arr, t_peak, has_pk,
+                       learn_hp, intensity=None, heterogeneous=True, hp=None):
+    """grid_surface with the rollouts' agents learning (WorldToy.scala:147-167): learn_hp is a LearnHyper,
+    intensity[c] the gradAccumSteps of country c (1 when None)."""
+    n = len(pops)
+    pops = np.ascontiguousarray(pops, dtype=np.int32)
+    betas = np.ascontiguousarray(betas, dtype=np.float64); tss = np.ascontiguousarray(tss, dtype=np.float64)
+    ta = np.ascontiguousarray(t_arrive, dtype=np.float64); tp = np.ascontiguousarray(t_peak, dtype=np.float64)
+    ha = np.ascontiguousarray(has_arr, dtype=np.uint8); hk = np.ascontiguousarray(has_pk, dtype=np.uint8)
+    hp = hp or default_hyper()
+    it = np.ascontiguousarray(intensity if intensity is not None else np.ones(n), dtype=np.int32)
+    G = len(betas) * len(tss)
+    loss = np.zeros(G); arr = np.zeros((G, n), dtype=np.int32); pk = np.zeros((G, n))
+    bi = C.c_int32(0); bl = C.c_double(0)
+    W = np.ascontiguousarray(W, dtype=np.float64)
+    err = lib().orc_grid_surface_learn(C.c_int32(n), _p(pops, C.c_int32), _p(W, C.c_double), C.c_int32(seed_idx), C.byref(base),
+                                       profiles_array(profiles), C.byref(hp), C.c_int32(steps), _p(betas, C.c_double),
+                                       C.c_int32(len(betas)), _p(tss, C.c_double), C.c_int32(len(tss)), _p(ta, C.c_double),
+                                       _p(ha, C.c_uint8), _p(tp, C.c_double), _p(hk, C.c_uint8), C.c_int32(int(heterogeneous)),
+                                       _p(loss, C.c_double), _p(arr, C.c_int32), _p(pk, C.c_double), C.byref(bi), C.byref(bl),
+                                       C.byref(learn_hp), _p(it, C.c_int32))
+    return dict(loss=loss, arrival=arr, peak=pk, best_idx=bi.value, best_loss=bl.value, err=err)
+
+
 def bench_points(pops, W, seed_idx, base, profiles, steps, betas, tss, heterogeneous, g0, n_points, hp=None):
     n = len(pops)
     pops = np.ascontiguousarray(pops, dtype=np.int32)

@@ -311,3 +311,88 @@ def test_transitions_filed_on_the_device(epi):
         w2 = epi.WorldToy(hp, base, batch=1, learning=False)
         pa.observe_world(w2)
     w.close(); pa.close(); pb.close()
+
+
+# ---------------------------------------------------------------- calibration sweeps whose rollouts learn
+def _toy_sweep(epi, hp, steps, betas, travel, heterogeneous=True):
+    from epidemicsimulator_amd import synth
+    wl = dict(synth.workload("c1"), steps=steps, betas=betas, travel=travel)
+    names = [c.name for c in wl["countries"]]
+    intensity = [epi.WorldToy.LEARNING_INTENSITY.get(nm, 1) for nm in names]
+    assert intensity == [1, 1, 2, 1, 1, 1] or sorted(intensity) == [1, 1, 1, 1, 1, 2]   # India learns twice as hard
+    base = synth.base_state(steps)
+    got = util.engine_grid(wl, base, heterogeneous, hp=hp, names=names)
+    want = util.oracle_grid_learn(wl, base, hp, intensity, heterogeneous)
+    return wl, base, got, want
+
+
+def test_toy_sweep_600_steps_small_batches_equals_the_learning_oracle(epi):
+    """The toy set with rollouts twice the default length and batchSize 8: the agents learn from step 32 on, every 8
+    steps, and the episodes take argmax Q at act-calls 114 and 456 (DDQNAgent.scala:26-32) -- on trained weights,
+    one network per (grid point, country).  Integers bit-exact, losses within 1e-12."""
+    hp = epi.HyperParams(batch_size=8)
+    wl, base, got, want = _toy_sweep(epi, hp, 600, [0.24, 0.26, 0.27], [0.5, 0.8, 0.9])
+    util.assert_grid_equal(got, want)
+    # the public entry point, learningIntensity taken from the country names
+    rows, (best, pair) = epi.Calibrate.grid_surface(hp, epi.TrainConfig(steps_per_epoch=600), base, 0,
+                                                    epi.Calibrate.Targets({c.name: wl["t_arrive"][k] for k, c in enumerate(wl["countries"])},
+                                                                          {c.name: wl["t_peak"][k] for k, c in enumerate(wl["countries"])}),
+                                                    wl["betas"], wl["travel"])
+    np.testing.assert_allclose([r[2] for r in rows], want["loss"], rtol=1e-12, atol=0)
+    assert abs(best - want["best_loss"]) <= 1e-12 * want["best_loss"]
+
+
+@pytest.mark.parametrize("hidden,hetero,bs,every,eps0,lr", [(128, True, 4, 2, 0.3, 1e-2), (64, False, 2, 1, 0.2, 1e-1),
+                                                            (24, True, 8, 5, 0.6, 5e-3)])
+def test_toy_sweep_with_frequent_argmax_steps_equals_the_learning_oracle(epi, hidden, hetero, bs, every, eps0, lr):
+    """Epsilon decays from eps0 to 0.05 within 100 steps and learning starts after 4 * batchSize steps, so most of the
+    220 steps ask networks that have been trained: the trajectories depend on every learn call.  The sweep must differ
+    from the one with untrained networks (otherwise the test shows nothing) and equal the learning oracle."""
+    hp = epi.HyperParams(batch_size=bs, learn_every=every, hidden=hidden, epsilon_start=eps0, epsilon_end=0.05,
+                         epsilon_decay_steps=100, target_update_every=10, lr=lr, grad_clip=5.0)
+    wl, base, got, want = _toy_sweep(epi, hp, 220, [0.25, 0.27], [0.6, 0.9], hetero)
+    util.assert_grid_equal(got, want)
+    ohp, _ = util.oracle_hypers(hp)
+    n = 6
+    ta = np.zeros(n); tp = np.zeros(n); ha = np.zeros(n, dtype=np.uint8); hk = np.zeros(n, dtype=np.uint8)
+    for c, v in wl["t_arrive"].items():
+        ta[c], ha[c] = v, 1
+    for c, v in wl["t_peak"].items():
+        tp[c], hk[c] = v, 1
+    untrained = O.grid_surface([c.pop for c in wl["countries"]], wl["conn"], 0, util.oracle_state(base),
+                               [util.prof_dict(p) for p in wl["profiles"]], 220, wl["betas"], wl["travel"], ta, ha, tp, hk, hetero, hp=ohp)
+    assert untrained["err"] == 3 and (untrained["peak"] != want["peak"]).any(), "learning changes the trajectories"
+
+
+def test_learning_sweep_refusals(epi):
+    """Without the learn step's hyper-parameters in the descriptor, for sparse worlds, through the allocation-free
+    entry point and beyond 16,384 agents per call a sweep that would consult trained weights is refused."""
+    import ctypes as C
+    from epidemicsimulator_amd import synth, _capi
+    import epidemicsimulator_amd as E
+    hp = epi.HyperParams(batch_size=8, epsilon_start=0.5, epsilon_end=0.5)
+    wl = synth.small_workload(20, 2, 2, 60, seed=5)
+    d, keep = E._grid_desc(hp, 60, synth.base_state(60), 0, [c.pop for c in wl["countries"]], wl["conn"], wl["profiles"],
+                           E.f64(wl["betas"]), E.f64(wl["travel"]), wl["t_arrive"], wl["t_peak"], True, 0)
+    d.learn = None
+    assert not E.lib().epi_grid_create(C.byref(d))
+    assert E.lib().epi_last_status() == _capi.EPI_ERR_UNSUPPORTED and "epi_grid_desc.learn" in _capi.last_error()
+    countries, xy = synth.make_countries(1100, 3)
+    sp = dict(wl, countries=countries, profiles=countries, conn=synth.gravity_csr(countries, xy, 3, mean_degree=5.0))
+    sp["t_arrive"], sp["t_peak"] = synth.targets(1100, 60, 3)
+    with pytest.raises(epi.EpiError) as ei:
+        util.engine_grid(sp, synth.base_state(60), True, hp=hp)
+    assert ei.value.status == _capi.EPI_ERR_UNSUPPORTED and "dense worlds" in ei.value.message
+    big = synth.small_workload(20, 30, 30, 60, seed=5)             # 900 grid points x 20 countries = 18,000 agents
+    eng = epi.GridEngine(hp, 60, synth.base_state(60), 0, [c.pop for c in big["countries"]], big["conn"], big["profiles"],
+                         big["betas"], big["travel"], big["t_arrive"], big["t_peak"], True)
+    with pytest.raises(epi.EpiError) as ei:
+        eng.run(want_metrics=False)
+    assert ei.value.status == _capi.EPI_ERR_UNSUPPORTED and "16384" in ei.value.message
+    part = eng.run(0, 4)                                           # the same handle takes a smaller call
+    assert np.isfinite(part["loss"]).all()
+    loss = util.DeviceArray(4, np.float64, -7.0)
+    with pytest.raises(epi.EpiError) as ei:
+        eng.enqueue_noalloc(0, 4, loss.ptr)
+    assert ei.value.status == _capi.EPI_ERR_UNSUPPORTED
+    eng.close()
