@@ -845,6 +845,12 @@ class WorldToy:
         check(lib().epi_world_kernel_time(self._h, C.byref(ms), C.byref(k), C.byref(cs)))
         return ms.value, k.value, cs.value
 
+    def screen_stats(self) -> Tuple[int, int]:
+        """(states the argmax screen looked at, states it sent to the exact evaluation) since set_mlp."""
+        a = C.c_int64(0); b = C.c_int64(0)
+        check(lib().epi_world_screen_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_mlp(self, W1, W2, W3, b1=None, b2=None, b3=None, clip_q=None):
         W1, W2, W3 = f64(W1), f64(W2), f64(W3)
         bs = [None if b is None else f64(b) for b in (b1, b2, b3)]
@@ -1082,6 +1088,12 @@ class GridEngine:
 
     def status(self):
         check(lib().epi_grid_status(self._h))
+
+    def screen_stats(self) -> Tuple[int, int]:
+        """(states the argmax screen looked at, states it sent to the exact evaluation) by this engine so far."""
+        a = C.c_int64(0); b = C.c_int64(0)
+        check(lib().epi_grid_screen_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_timing(self, on: bool):
         check(lib().epi_grid_set_timing(self._h, int(on)))

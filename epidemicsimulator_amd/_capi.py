@@ -85,7 +85,7 @@ EXPORTED_SYMBOLS = [
     "epi_version", "epi_last_error", "epi_last_status", "epi_device_count", "epi_set_device", "epi_alloc_int", "epi_alloc_int_batch",
     "epi_env_step_batch", "epi_scale_row", "epi_gravity_matrix", "epi_gravity_csr", "epi_java_gaussians", "epi_java_gaussian_table", "epi_agent_actions", "epi_mlp_init",
     "epi_mlp_greedy_batch", "epi_grid_create", "epi_grid_run", "epi_grid_run_strided", "epi_grid_run_noalloc", "epi_grid_status", "epi_grid_destroy",
-    "epi_grid_argmin", "epi_calibrate_grid", "epi_grid_multi_create", "epi_grid_multi_run", "epi_grid_multi_ranks",
+    "epi_grid_argmin", "epi_grid_screen_stats", "epi_world_screen_stats", "epi_calibrate_grid", "epi_grid_multi_create", "epi_grid_multi_run", "epi_grid_multi_ranks",
     "epi_grid_multi_set_timing", "epi_grid_multi_times", "epi_grid_multi_peer_access", "epi_grid_multi_inject_failure",
     "epi_grid_multi_destroy", "epi_calibrate_grid_multi", "epi_grid_set_timing", "epi_grid_kernel_time", "epi_world_create", "epi_world_step", "epi_world_step_greedy", "epi_world_rollout_greedy", "epi_world_keep_transitions",
     "epi_world_set_mlp", "epi_world_get_states", "epi_world_set_states", "epi_world_reset", "epi_world_last_flows",
@@ -131,6 +131,8 @@ def lib():
         L.epi_grid_multi_peer_access.argtypes = [C.c_void_p, _PU8]
         L.epi_grid_multi_inject_failure.argtypes = [C.c_void_p, C.c_int32]
         L.epi_calibrate_grid_multi.argtypes = [C.POINTER(GridDesc), _PI, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, _PI, _PD]
+        L.epi_grid_screen_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.epi_world_screen_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.epi_grid_set_timing.argtypes = [C.c_void_p, C.c_int32]
         L.epi_grid_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.epi_world_result_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),

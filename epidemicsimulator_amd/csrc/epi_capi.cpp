@@ -457,6 +457,8 @@ struct MlpDevice {
         std::vector<double> img(nl.size());
         pack_net(nl, w1, bb1, w2, bb2, w3, bb3, img.data());
         HIP_TRY(net.upload(img));
+        HIP_TRY(screen_stats.ensure(2 * sizeof(unsigned long long)));   // states screened / flagged since this upload
+        HIP_TRY(hipMemset(screen_stats.p, 0, 2 * sizeof(unsigned long long)));
         // constants of the screen pass's error bound (MlpArgs::cert): largest absolute row sum and bias per layer
         auto norms = [](const double* w, const double* b, int rows, int cols, double& A, double& B) {
             A = B = 0.0;
@@ -481,6 +483,17 @@ struct MlpDevice {
     int certify = 0;
     double cert[6] = {0, 0, 0, 0, 0, 0};
     double cert_scale = 1.0;
+    DevBuf screen_stats;
+    int32_t read_stats(int64_t* screened, int64_t* flagged) const {
+        unsigned long long h[2] = {0, 0};
+        if (screen_stats.p) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipMemcpy(h, screen_stats.p, sizeof h, hipMemcpyDeviceToHost));
+        }
+        if (screened) *screened = (int64_t)h[0];
+        if (flagged) *flagged = (int64_t)h[1];
+        return EPI_OK;
+    }
     void fill(MlpArgs& a) const {
         a.nl = nl;
         a.nets = net.as<double>();
@@ -492,6 +505,7 @@ struct MlpDevice {
         a.certify = certify;
         for (int k = 0; k < 6; ++k) a.cert[k] = cert[k];
         a.cert_scale = cert_scale;
+        a.cert_stats = screen_stats.as<unsigned long long>();
     }
 };
 
@@ -2005,6 +2019,18 @@ void world_transition_consumed(epi_world* w) {
     if (w) w->have_tr = false;
 }
 }  // namespace epi
+
+EPI_API int32_t epi_world_screen_stats(epi_world* w, int64_t* screened, int64_t* flagged) {
+    if (!w) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_screen_stats: null handle");
+    HIP_TRY(hipSetDevice(w->device));
+    return w->mlp.read_stats(screened, flagged);
+}
+
+EPI_API int32_t epi_grid_screen_stats(epi_grid* g, int64_t* screened, int64_t* flagged) {
+    if (!g) return fail(EPI_ERR_BAD_ARGUMENT, "epi_grid_screen_stats: null handle");
+    HIP_TRY(hipSetDevice(g->device));
+    return g->mlp.read_stats(screened, flagged);
+}
 
 EPI_API int32_t epi_world_set_timing(epi_world* w, int32_t on) {
     if (!w) return fail(EPI_ERR_BAD_ARGUMENT, "epi_world_set_timing: null handle");

@@ -1868,6 +1868,7 @@ __global__ __launch_bounds__(MLP_TILE_THREADS) void mlp_tile_kernel(const MlpArg
         }
     }
     __syncthreads();
+    int unsure = 0, live = 0;   // MODE 1: this thread's state was looked at / was flagged
     if (tid < MLP_TILE_ROWS) {
         int e, c;
         if (locate(tid, e, c)) {
@@ -1885,15 +1886,31 @@ __global__ __launch_bounds__(MLP_TILE_THREADS) void mlp_tile_kernel(const MlpArg
                 const double H1 = A1 * X + B1, e1 = g8 * H1;
                 const double H2 = A2 * H1 + B2, e2 = A2 * e1 + gh * (A2 * (H1 + e1) + B2);
                 const double e3 = A3 * e2 + gh * (A3 * (H2 + e2) + B3);
-                // (the floor covers products that underflow, which the relative bound does not see: at most a few
-                // hundred roundings of 2^-1074 each; the comparison is false for NaN as well)
-                const bool sure = (sh_y[tid][best] - second) > 4.0 * e3 * a.cert_scale + 1e-300;
+                // The floor covers what the relative bound does not see: products and sums that underflow.  With gradual
+                // underflow that is a few hundred roundings of 2^-1074; should the matrix cores flush subnormal
+                // operands or results to zero instead, each of the HP products of a second-layer sum may be off by up
+                // to the smallest normal number, 2.3e-308, which the third layer scales by at most A3 (and the first
+                // layer's own flushes by A2 A3).  1e-300 (1 + A2)(1 + A3) is far above either and far below any margin
+                // that matters.  The comparison is false for NaN as well.
+                const double floor_abs = 1e-300 * (1.0 + A2) * (1.0 + A3);
+                const bool sure = (sh_y[tid][best] - second) > 4.0 * e3 * a.cert_scale + floor_abs;
                 a.act_episode[(size_t)e * a.npad + c] = (int8_t)(sure ? best : (best | kActUncertain));
+                unsure = !sure;
+                live = 1;
             } else {
                 if (a.act_episode) a.act_episode[(size_t)e * a.npad + c] = (int8_t)best;
                 if (a.act_out) a.act_out[row] = best;
                 if (a.q_out)
                     for (int o = 0; o < 8; ++o) a.q_out[row * 8 + o] = sh_y[tid][o];
+            }
+        }
+    }
+    if constexpr (MODE == 1) {
+        if (a.cert_stats && tid < 64) {   // the tile's states sit in the first wave (MLP_TILE_ROWS <= 64): one pair of atomics per tile
+            const int n_live = __popcll(__ballot(live)), n_unsure = __popcll(__ballot(unsure));
+            if (tid == 0) {
+                atomicAdd(&a.cert_stats[0], (unsigned long long)n_live);
+                if (n_unsure) atomicAdd(&a.cert_stats[1], (unsigned long long)n_unsure);
             }
         }
     }

@@ -184,6 +184,7 @@ struct MlpArgs {
     int certify;
     double cert[6];
     double cert_scale;
+    unsigned long long* cert_stats;   // optional [2]: states the screen looked at, states it flagged for the exact pass
 };
 constexpr int8_t kActUncertain = 0x40;   // flag on an act_episode entry between the screen and the exact pass
 

@@ -230,6 +230,11 @@ int32_t epi_grid_destroy(epi_grid *g);
  * was switched on. */
 int32_t epi_grid_set_timing(epi_grid *g, int32_t on);
 int32_t epi_grid_kernel_time(epi_grid *g, double *total_ms, int64_t *launches, int64_t *country_steps);
+/* Diagnostics (no counterpart in the reference).  The argmax-Q step of a large batch first screens the states with
+ * fused arithmetic and re-evaluates, in the reference's operation order, those whose first maximum the screen's error
+ * bound cannot certify: screened = states the screen looked at, flagged = states it sent to the exact evaluation,
+ * both since the handle's network was uploaded (0, 0 when the screen is off or was never used). */
+int32_t epi_grid_screen_stats(epi_grid *g, int64_t *screened, int64_t *flagged);
 /* First minimum in flat order with strict '<' starting from Double.MaxValue (Calibrate.scala:96,112). */
 int32_t epi_grid_argmin(const double *loss, int32_t count, int32_t *best_idx, double *best_loss);
 /* gridSurface in one call on one device: loss[n_beta*n_travel] beta-major; arrival/peak optional. */
@@ -350,6 +355,8 @@ int32_t epi_world_set_states(epi_world *w, const epi_state *in);
 int32_t epi_world_reset(epi_world *w);                            /* resetToInitial :77 */
 /* Net S and I flows of the last step, movedS/movedI[batch][n] (WorldToy.scala:106-126). */
 int32_t epi_world_last_flows(epi_world *w, int32_t *moved_s, int32_t *moved_i);
+/* As epi_grid_screen_stats, for the network of epi_world_set_mlp (batched greedy steps). */
+int32_t epi_world_screen_stats(epi_world *w, int64_t *screened, int64_t *flagged);
 /* Measurement hooks (no counterpart in the reference), as epi_grid_set_timing / epi_grid_kernel_time. */
 int32_t epi_world_set_timing(epi_world *w, int32_t on);
 int32_t epi_world_kernel_time(epi_world *w, double *total_ms, int64_t *launches, int64_t *country_steps);

@@ -42,6 +42,7 @@ object Epi {
   val gridDestroy = fn("epi_grid_destroy", JAVA_INT, ADDRESS)
   val gridSetTiming = fn("epi_grid_set_timing", JAVA_INT, ADDRESS, JAVA_INT)
   val gridKernelTime = fn("epi_grid_kernel_time", JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS)
+  val gridScreenStats = fn("epi_grid_screen_stats", JAVA_INT, ADDRESS, ADDRESS, ADDRESS)
   val gridArgmin = fn("epi_grid_argmin", JAVA_INT, ADDRESS, JAVA_INT, ADDRESS, ADDRESS)
   val calibrateGrid = fn("epi_calibrate_grid", JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS)
   val gridMultiCreate = fn("epi_grid_multi_create", ADDRESS, ADDRESS, ADDRESS, JAVA_INT)
@@ -66,6 +67,7 @@ object Epi {
   val worldSetStates = fn("epi_world_set_states", JAVA_INT, ADDRESS, ADDRESS)
   val worldReset = fn("epi_world_reset", JAVA_INT, ADDRESS)
   val worldLastFlows = fn("epi_world_last_flows", JAVA_INT, ADDRESS, ADDRESS, ADDRESS)
+  val worldScreenStats = fn("epi_world_screen_stats", JAVA_INT, ADDRESS, ADDRESS, ADDRESS)
   val worldSetTiming = fn("epi_world_set_timing", JAVA_INT, ADDRESS, JAVA_INT)
   val worldKernelTime = fn("epi_world_kernel_time", JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS)
   val worldDestroy = fn("epi_world_destroy", JAVA_INT, ADDRESS)
