@@ -154,7 +154,8 @@ def run_c5(args, rank, local_rank, world, use_dist):
     import epidemicsimulator_amd as E
     from epidemicsimulator_amd import synth
 
-    B, beta = 4096, 0.26
+    B = 4096
+    beta, _travel = synth.calibrated_toy_point(local_rank)   # "the calibrated config": the C1 sweep's first minimum, computed here
     countries = list(E.ToyConn.C)
     n = len(countries)
 
@@ -212,11 +213,13 @@ def run_c5(args, rank, local_rank, world, use_dist):
         "value": float(world) * B * n * args.steps / elapsed, "unit": "country-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(1, args.steps) * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": ("c5: %d instances of the %d-country toy world, one world step per iteration, actions in, "
-                                "states%s and rewards out over PCIe every step" % (B, n, " (32-byte records)" if packed else ""))
+        "config": {"workload": ("c5: %d instances of the %d-country toy world at the calibrated beta %.2f, one world step per "
+                                "iteration, actions in, states%s and rewards out over PCIe every step"
+                                % (B, n, beta, " (32-byte records)" if packed else ""))
                                if not resident else
-                               ("c5: %d instances of the %d-country toy world, one world step per iteration, actions in, states "
-                                "and rewards left on the device (NULL outputs)" % (B, n)),
+                               ("c5: %d instances of the %d-country toy world at the calibrated beta %.2f, one world step per "
+                                "iteration, actions in, states and rewards left on the device (NULL outputs)" % (B, n, beta)),
+                   "calibrated_beta": beta,
                    "instances_per_gpu": B, "country_steps_per_step": world * B * n,
                    "parallelism": "independent replicas" if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -129,3 +129,20 @@ def small_workload(n: int, n_beta: int, n_travel: int, steps: int, seed: int = D
     return dict(name="small", countries=countries, profiles=countries, conn=gravity_dense(countries, xy), steps=steps,
                 betas=np.linspace(0.20, 0.40, n_beta).tolist(), travel=np.linspace(0.25, 2.0, n_travel).tolist(),
                 t_arrive=ta, t_peak=tp, seed_idx=0)
+
+
+def calibrated_toy_point(device: int = 0):
+    """(beta, travel scale) the default calibration picks for the toy world: the first minimum of configuration 1's
+    4 x 5 surface (App.scala:97-109), computed by the engine's own sweep.  Configuration 5 -- the batched DDQN
+    rollout "of the calibrated config" -- takes its beta from here instead of a constant."""
+    import epidemicsimulator_amd as E
+    wl = workload("c1")
+    eng = E.GridEngine(E.HyperParams(), wl["steps"], base_state(wl["steps"]), wl["seed_idx"], [c.pop for c in wl["countries"]],
+                       wl["conn"], wl["profiles"], wl["betas"], wl["travel"], wl["t_arrive"], wl["t_peak"], True, device=device)
+    try:
+        loss = eng.run(want_metrics=False)["loss"]
+    finally:
+        eng.close()
+    best, _ = E.grid_argmin(loss)
+    nt = len(wl["travel"])
+    return float(wl["betas"][best // nt]), float(wl["travel"][best % nt])

@@ -390,9 +390,22 @@ def test_world_step_one_and_greedy_follow_reference_streams(epi):
         assert a_series == b_series       # EvalDeterminismSpec.scala:37-45
 
 
-def _c5_world(epi, batch, beta=0.26):
+def oracle_best_beta():
+    """Best beta of configuration 1's surface according to the oracle's own sweep."""
+    from epidemicsimulator_amd import synth
+    wl = synth.workload("c1")
+    want = util.oracle_grid(wl, synth.base_state(wl["steps"]))
+    return wl["betas"][want["best_idx"] // len(wl["travel"])]
+
+
+def _c5_world(epi, batch, beta=None):
     """Configuration 5: `batch` instances of the six-country toy world with the heterogeneous env parameters of
-    Calibrate.scala:34-51 at the calibrated beta (bench.py's c5 workload)."""
+    Calibrate.scala:34-51 at the calibrated beta -- the first minimum of configuration 1's surface, computed by the
+    engine's sweep (bench.py's c5 workload takes it from the same place)."""
+    from epidemicsimulator_amd import synth
+    if beta is None:
+        beta, _ = synth.calibrated_toy_point()
+        assert beta == oracle_best_beta()
     countries = list(epi.ToyConn.C)
     names = [c.name for c in countries]
 
