@@ -330,7 +330,18 @@ struct InflowWords {
     __device__ __forceinline__ uint32_t& operator[](int c) const { return p[2 * c]; }
 };
 
-constexpr int kCsrThreads = 768;  // 12 waves, 3 per SIMD: ~170 registers per lane for the keys of two compartments
+// 16 waves, 4 per SIMD, within 128 registers per lane.  The 32-slot mobility routine holds the keys of one compartment at
+// a time to stay inside that budget (it serves few blocks: rows are sorted by length); the 16- and 24-slot routines keep
+// the keys of both compartments side by side.  Measured on the 20,000-patch sweep: 768 threads / 153 registers 16.25 ms
+// per launch; 1,024 threads with every routine in two passes 15.9 ms; with only the 32-slot routine in two passes 15.3 ms
+// (the fourth wave per SIMD shortens the local / apply pass by 17 %, the mobility phase not at all).
+#ifndef EPI_CSR_THREADS
+#define EPI_CSR_THREADS 1024
+#endif
+#ifndef EPI_CSR_TWO_PASS
+#define EPI_CSR_TWO_PASS 32   // routines of at least this many slots form the S and the I keys one after the other (0 = none)
+#endif
+constexpr int kCsrThreads = EPI_CSR_THREADS;
 
 // Slots are read in groups of kSlotGroup: a group is skipped when the block has no such slots, and all
 // loads of the groups that are read are issued before the first one is consumed.  Every block's slot
@@ -436,9 +447,46 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
     // slots are worked on in chunks of whole groups: all loads of a chunk are in flight together
     constexpr int HALF = (DMAX % (2 * kSlotGroup) == 0) ? DMAX / 2 : kSlotGroup;
     const double EdS = (double)ES, EdI = (double)EI;
+    EPI_TM(long long c0 = clock64();)
+    constexpr bool kTwoPass = EPI_CSR_TWO_PASS > 0 && DMAX >= EPI_CSR_TWO_PASS;
+    LaneThreshold thS, thI;
+    thI.Kx = 0xffffffffu;
+    thI.picked = 0u;
+    thI.bad = false;
+    if constexpr (kTwoPass) {
+    // One compartment at a time: the keys of one compartment (DMAX registers) instead of two live side by side, at
+    // the price of a third read of the block's weights in blocks that export infectious people.
+    auto threshold_of = [&](double Ed, int32_t E) {
+        uint32_t key[DMAX];
+        uint32_t bsum = 0u;
+#pragma unroll
+        for (int h0 = 0; h0 < DMAX; h0 += HALF) {
+            double qv[HALF];
+#pragma unroll
+            for (int k0 = 0; k0 < HALF; k0 += kSlotGroup) {
+#pragma unroll
+                for (int j = 0; j < kSlotGroup; ++j) qv[k0 + j] = 0.0;
+                if (h0 + k0 < D) {
+                    const double* qg = group_ptr(qp, h0 + k0);
+#pragma unroll
+                    for (int j = 0; j < kSlotGroup; ++j) qv[k0 + j] = qg[j * 64];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < HALF; ++j) {
+                const double raw = qv[j] * Ed;  // slots past D of a group that is read hold weight 0
+                bsum += (uint32_t)(int32_t)raw;
+                key[h0 + j] = (uint32_t)__double2hiint(frac_of(raw));
+            }
+        }
+        const int32_t rem = (int32_t)((uint32_t)E - bsum);
+        return lane_threshold<DMAX>(key, rem, Ed, D, qp);
+    };
+    thS = threshold_of(EdS, ES);
+    if (anyI) thI = threshold_of(EdI, EI);
+    } else {
     uint32_t keyS[DMAX], keyI[DMAX];
     uint32_t bsumS = 0u, bsumI = 0u;
-    EPI_TM(long long c0 = clock64();)
 #pragma unroll
     for (int h0 = 0; h0 < DMAX; h0 += HALF) {
         double qv[HALF];
@@ -465,12 +513,9 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
     }
     const int32_t remS = (int32_t)((uint32_t)ES - bsumS), remI = (int32_t)((uint32_t)EI - bsumI);
     EPI_TM(asm volatile("" ::"v"(remS), "v"(remI)); { const long long c1 = clock64(); tm[0] += c1 - c0; c0 = c1; })
-    const LaneThreshold thS = lane_threshold<DMAX>(keyS, remS, EdS, D, qp);
-    LaneThreshold thI;
-    thI.Kx = 0xffffffffu;
-    thI.picked = 0u;
-    thI.bad = false;
+    thS = lane_threshold<DMAX>(keyS, remS, EdS, D, qp);
     if (anyI) thI = lane_threshold<DMAX>(keyI, remI, EdI, D, qp);
+    }
     if (thS.bad || thI.bad) record_error(sh_err, EPI_ERR_UNSUPPORTED, row, t);
     EPI_TM(asm volatile("" ::"v"(thS.Kx), "v"(thI.Kx)); { const long long c1 = clock64(); tm[1] += c1 - c0; c0 = c1; })
     // A unit lands only on stored off-diagonal entries: padding and a stored diagonal hold weight 0, hence
@@ -733,7 +778,7 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
         if (tid == 0) *sh_next = 0;
         unsigned long long mass_local = 0ull, mass_move = 0ull;
         // The inputs of a thread's next patch are fetched before the current one is worked on: a thread
-        // visits about n / 768 patches per step and would otherwise expose one memory latency for each.
+        // visits about n / 1024 patches per step and would otherwise expose one memory latency for each.
         struct PatchIn {
             int32_t s, i, r, d, v, tc, es, ei, arr, pk, pos;
             uint32_t ms, mi;

@@ -1,0 +1,7 @@
+# A/B of libepi variants on the sparse workload: tools/ab_c4.sh <variant> ... ("base" = the in-tree library)
+for v in "$@"; do
+  if [ "$v" = base ]; then unset EPI_LIB; else export EPI_LIB=$PWD/build/libepi_$v.so; fi
+  for rep in 1 2; do
+    timeout -k 10 200 python bench.py --workload c4 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/ab_$v.$rep.json 2> gpurun_out/ab_$v.$rep.err || exit 1
+  done
+done
