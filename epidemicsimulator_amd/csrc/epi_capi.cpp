@@ -119,7 +119,6 @@ struct GraphTables {
     int n_blocks = 0;
     std::vector<int32_t> h_rowptr, h_col;
     std::vector<double> h_val;
-    std::vector<double> h_ell_q;          // host copy of the ELL weights (seed-block variants are cut from it)
     // A sweep numbers the patches of a sparse graph in lane-layout order inside the engine (renumbered): internal id
     // p < n_ell is the row at position p of the length-sorted blocks, the long rows follow.  A block of 64 rows is then
     // 64 consecutive patches: the mobility phase reads the exports and the local phase writes them with coalesced
@@ -151,27 +150,40 @@ struct GraphTables {
         return EPI_OK;
     }
 
+    // Weights of one ELL block (slot-major, whole slot groups) read back from the device: the seed row's block, of
+    // which a sweep keeps one copy per travel scale.
+    int32_t download_block_q(int b, std::vector<double>& out) const {
+        const size_t slots = (size_t)(h_slots[(size_t)b] + kSlotGroup - 1) / kSlotGroup * kSlotGroup;
+        out.assign(slots * 64, 0.0);
+        if (slots == 0) return EPI_OK;
+        HIP_TRY(hipMemcpy(out.data(), d_qval.as<double>() + (size_t)h_off[(size_t)b] * 64, slots * 64 * sizeof(double), hipMemcpyDeviceToHost));
+        return EPI_OK;
+    }
+
     int32_t build_sparse(const int32_t* pop_, const double* conn, const int32_t* rowptr, const int32_t* col,
                          const double* val, bool renumber) {
         sparse = true;
         npad = (n + 63) / 64 * 64;
         if (csr_lds_bytes(n) > kMaxLdsBytes)
             return fail(EPI_ERR_UNSUPPORTED, "n = %d patches: the sparse kernel keeps 8 bytes of inflow per patch in the %zu KiB of LDS", n, kMaxLdsBytes / 1024);
+        // host copy of the graph in CSR form: checked here, and the seed-row variants of a sweep are cut from it
         h_rowptr.assign((size_t)n + 1, 0);
         h_col.clear();
         h_val.clear();
         if (rowptr && col && val) {
+            if (rowptr[n] < rowptr[0]) return fail(EPI_ERR_BAD_ARGUMENT, "CSR row pointers must be ascending");
             for (int i = 0; i < n; ++i) {
+                if (rowptr[i + 1] < rowptr[i]) return fail(EPI_ERR_BAD_ARGUMENT, "CSR row pointers must be ascending (row %d)", i);
                 int prev = -1;
                 for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
                     if (col[k] < 0 || col[k] >= n || col[k] <= prev)
                         return fail(EPI_ERR_BAD_ARGUMENT, "CSR row %d: column indices must be ascending and in [0,n)", i);
                     prev = col[k];
-                    h_col.push_back(col[k]);
-                    h_val.push_back(val[k]);
                 }
-                h_rowptr[i + 1] = (int32_t)h_col.size();
+                h_rowptr[(size_t)i + 1] = rowptr[i + 1] - rowptr[0];
             }
+            h_col.assign(col + rowptr[0], col + rowptr[n]);
+            h_val.assign(val + rowptr[0], val + rowptr[n]);
         } else if (conn) {
             for (int i = 0; i < n; ++i) {
                 for (int j = 0; j < n; ++j)
@@ -182,121 +194,135 @@ struct GraphTables {
             return fail(EPI_ERR_BAD_ARGUMENT, "neither a dense matrix nor a CSR triple was given");
         }
         max_deg = 0;
-        for (int i = 0; i < n; ++i) max_deg = std::max(max_deg, h_rowptr[i + 1] - h_rowptr[i]);
-        std::vector<double> hq(h_val.size() ? h_val.size() : 1, 0.0), hs((size_t)npad, 0.0);
         for (int i = 0; i < n; ++i) {
-            const int rs = h_rowptr[i], deg = h_rowptr[i + 1] - rs;
-            int32_t rc = normalise_sparse_row(h_val.data() + rs, h_col.data() + rs, deg, i, hq.data() + rs, &hs[i]);
-            if (rc) return rc;
+            const int rs = h_rowptr[i], re = h_rowptr[i + 1];
+            max_deg = std::max(max_deg, re - rs);
+            for (int k = rs; k < re; ++k) {
+                const double w = h_val[(size_t)k];
+                if (h_col[(size_t)k] != i && (!std::isfinite(w) || w < 0.0))
+                    return fail(EPI_ERR_BAD_ARGUMENT, "connection weight (%d,%d) = %g: weights must be finite and >= 0", i, h_col[(size_t)k], w);
+            }
         }
         for (int c = 0; c < n; ++c)
             if (pop_[c] < 0) return fail(EPI_ERR_BAD_ARGUMENT, "pop[%d] = %d is negative", c, pop_[c]);
-        // Slot-major blocks of 64 rows: one lane per row reads its k-th weight with a coalesced load.  The rows
-        // a lane can hold are sorted by length, longest first, before they are cut into blocks: a block then
-        // stores (and the kernel reads and sorts) about as many slots as its rows really have, and the work
-        // queue of the kernel hands out the expensive blocks first.
-        h_long_rows.clear();
-        std::vector<int32_t> order;
-        for (int i = 0; i < n; ++i) {
-            if (h_rowptr[i + 1] - h_rowptr[i] > kLaneSlots) h_long_rows.push_back(i);
-            else order.push_back(i);
+        const size_t nnz = h_col.size();
+        // Row order on the host (lengths only, a stable counting sort: O(n)): the rows a lane can hold sorted by length,
+        // longest first, rows of one length in index order, cut into blocks of 64 -- a block then stores (and the kernel
+        // reads and sorts) about as many slots as its rows really have, and the work queue hands out the expensive
+        // blocks first; the longer rows follow in index order.
+        std::vector<int32_t> order((size_t)n);
+        {
+            std::vector<int32_t> start((size_t)kLaneSlots + 2, 0);
+            auto bucket = [&](int i) { const int dg = h_rowptr[i + 1] - h_rowptr[i]; return dg > kLaneSlots ? kLaneSlots + 1 : dg; };
+            for (int i = 0; i < n; ++i) start[(size_t)bucket(i)] += 1;
+            int pos = 0;
+            std::vector<int32_t> cursor((size_t)kLaneSlots + 2, 0);
+            for (int dg = kLaneSlots; dg >= 0; --dg) { cursor[(size_t)dg] = pos; pos += start[(size_t)dg]; }
+            n_ell = pos;
+            cursor[(size_t)kLaneSlots + 1] = pos;
+            for (int i = 0; i < n; ++i) order[(size_t)cursor[(size_t)bucket(i)]++] = i;
         }
-        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-            return h_rowptr[x + 1] - h_rowptr[x] > h_rowptr[y + 1] - h_rowptr[y];
-        });
-        n_ell = (int)order.size();
-        renumbered = renumber;
-        id_of.clear(); orig_of.clear();
-        if (renumbered) {
-            id_of.assign((size_t)n, 0);
-            orig_of.assign((size_t)n, 0);
-            for (size_t p = 0; p < order.size(); ++p) id_of[(size_t)order[p]] = (int32_t)p;
-            for (size_t o = 0; o < h_long_rows.size(); ++o) id_of[(size_t)h_long_rows[o]] = (int32_t)(n_ell + (int)o);
-            for (int c = 0; c < n; ++c) orig_of[(size_t)id_of[(size_t)c]] = c;
-        }
-        std::vector<int32_t> hp((size_t)npad, 0);
-        std::vector<double> hs_in((size_t)npad, 0.0);   // row sums and populations in the engine's numbering
-        for (int c = 0; c < n; ++c) {
-            hp[(size_t)inner(c)] = pop_[c];
-            hs_in[(size_t)inner(c)] = hs[(size_t)c];
-        }
-        const int nblocks = ((int)order.size() + 63) / 64;
-        n_blocks = nblocks;
-        h_slots.assign((size_t)(nblocks > 0 ? nblocks : 1), 0);
-        h_off.assign((size_t)(nblocks > 0 ? nblocks : 1), 0);
-        h_pos.assign((size_t)n, -1);
-        std::vector<int32_t> rows((size_t)(nblocks > 0 ? nblocks : 1) * 64, -1);
+        const int n_long = n - n_ell;
+        n_blocks = (n_ell + 63) / 64;
+        h_slots.assign((size_t)(n_blocks > 0 ? n_blocks : 1), 0);
+        h_off.assign((size_t)(n_blocks > 0 ? n_blocks : 1), 0);
         int total_slots = 0;
-        lane_deg = 0;
-        for (int b = 0; b < nblocks; ++b) {
-            int dmax = 0;
-            for (int l = 0; l < 64 && b * 64 + l < (int)order.size(); ++l) {
-                const int i = order[(size_t)b * 64 + l];
-                rows[(size_t)b * 64 + l] = i;
-                h_pos[i] = b * 64 + l;
-                dmax = std::max(dmax, h_rowptr[i + 1] - h_rowptr[i]);
-            }
-            lane_deg = std::max(lane_deg, dmax);
-            h_slots[b] = dmax;
-            h_off[b] = total_slots;
-            total_slots += (dmax + kSlotGroup - 1) / kSlotGroup * kSlotGroup;  // whole slot groups, zero filled
+        for (int b2 = 0; b2 < n_blocks; ++b2) {
+            const int first = order[(size_t)b2 * 64];
+            const int dmax = h_rowptr[first + 1] - h_rowptr[first];   // a block's longest row is its first one
+            h_slots[(size_t)b2] = dmax;
+            h_off[(size_t)b2] = total_slots;
+            total_slots += (dmax + kSlotGroup - 1) / kSlotGroup * kSlotGroup;   // whole slot groups, zero filled
         }
-        std::vector<double> eq((size_t)(total_slots > 0 ? total_slots : 1) * 64, 0.0);
-        std::vector<int32_t> ec((size_t)(total_slots > 0 ? total_slots : 1) * 64, -1);
-        for (size_t p = 0; p < order.size(); ++p) {
-            const int i = order[p], b = (int)(p / 64), l = (int)(p % 64), rs = h_rowptr[i], deg = h_rowptr[i + 1] - rs;
-            for (int k = 0; k < deg; ++k) {
-                eq[((size_t)h_off[b] + k) * 64 + l] = hq[rs + k];
-                ec[((size_t)h_off[b] + k) * 64 + l] = inner(h_col[rs + k]);   // slots stay in the caller's column order
-            }
-        }
-        const size_t nl = h_long_rows.size();
-        std::vector<int32_t> lr(nl), lo(nl ? nl : 1, 0);
-        for (size_t o = 0; o < nl; ++o) lr[o] = inner(h_long_rows[o]);
+        lane_deg = n_blocks > 0 ? h_slots[0] : 0;
+        h_long_rows.assign(order.begin() + n_ell, order.end());
+        h_pos.assign((size_t)n, -1);
+        for (int p = 0; p < n_ell; ++p) h_pos[(size_t)order[(size_t)p]] = p;
+        // A sweep numbers the patches in this order inside the engine (see `renumbered`)
+        renumbered = renumber;
+        id_of.assign((size_t)n, 0);
+        for (int p = 0; p < n; ++p) id_of[(size_t)order[(size_t)p]] = p;
+        orig_of.clear();
+        if (renumbered) orig_of = order;
+        std::vector<int32_t> lo((size_t)(n_long ? n_long : 1), 0);
         size_t long_elems = 0;
-        for (size_t o = 0; o < nl; ++o) {
-            const int i = h_long_rows[o];
-            lo[o] = (int32_t)long_elems;
+        for (int o = 0; o < n_long; ++o) {
+            const int i = h_long_rows[(size_t)o];
+            lo[(size_t)o] = (int32_t)long_elems;
             long_elems += long_row_slots(h_rowptr[i + 1] - h_rowptr[i]);
         }
-        std::vector<double> lq(long_elems ? long_elems : 64, 0.0);
-        std::vector<int32_t> lc(long_elems ? long_elems : 64, -1);
-        for (size_t o = 0; o < nl; ++o) {
-            const int i = h_long_rows[o], rs = h_rowptr[i], deg = h_rowptr[i + 1] - rs;
-            for (int k = 0; k < deg; ++k) { lq[(size_t)lo[o] + k] = hq[rs + k]; lc[(size_t)lo[o] + k] = inner(h_col[rs + k]); }
-        }
-        if (lr.empty()) lr.push_back(0);
+        const size_t long_alloc = long_elems ? long_elems : 64;
+        const size_t ell_alloc = (size_t)(total_slots > 0 ? total_slots : 1) * 64;
+        // The tables the kernels read are allocated first, the staging of the build after them: where a buffer lands
+        // decides a few per cent of the sweep's speed, and this order is the one the measurements were made with.
         HIP_TRY(d_long_off.upload(lo));
-        HIP_TRY(d_long_rows.upload(lr));
-        HIP_TRY(d_long_q.upload(lq));
-        HIP_TRY(d_long_col.upload(lc));
+        HIP_TRY(d_long_rows.ensure(sizeof(int32_t) * (size_t)(n_long ? n_long : 1)));
+        HIP_TRY(d_long_q.ensure(sizeof(double) * long_alloc));
+        HIP_TRY(d_long_col.ensure(sizeof(int32_t) * long_alloc));
         {   // row lengths in the engine's numbering (the kernel reads them for the long rows)
             std::vector<int32_t> rp((size_t)n + 1, 0);
-            for (int c = 0; c < n; ++c) rp[(size_t)inner(c) + 1] = h_rowptr[c + 1] - h_rowptr[c];
+            for (int p = 0; p < n; ++p) {
+                const int c = order[(size_t)p];
+                rp[(size_t)(renumbered ? p : c) + 1] = h_rowptr[c + 1] - h_rowptr[c];
+            }
             for (int p = 0; p < n; ++p) rp[(size_t)p + 1] += rp[(size_t)p];
             HIP_TRY(d_rowptr.upload(rp));
         }
         std::vector<EllBlock> hb(h_slots.size());
-        for (size_t b = 0; b < hb.size(); ++b) {
-            hb[b].slots = h_slots[b];
-            hb[b].off = h_off[b];
+        for (size_t b2 = 0; b2 < hb.size(); ++b2) {
+            hb[b2].slots = h_slots[b2];
+            hb[b2].off = h_off[b2];
         }
         HIP_TRY(d_ell.upload(hb));
+        HIP_TRY(d_id_of.upload(id_of));
+        if (!renumbered) id_of.clear();
+        HIP_TRY(d_col.ensure(sizeof(int32_t) * ell_alloc));
+        HIP_TRY(d_qval.ensure(sizeof(double) * ell_alloc));
+        HIP_TRY(sumw.ensure(sizeof(double) * (size_t)npad));
+        HIP_TRY(pop.ensure(sizeof(int32_t) * (size_t)npad));
         if (renumbered) {
             d_ell_rows.release();
             d_ell_pos.release();
-            HIP_TRY(d_id_of.upload(id_of));
         } else {
+            std::vector<int32_t> rows((size_t)(n_blocks > 0 ? n_blocks : 1) * 64, -1);
+            std::copy(order.begin(), order.begin() + n_ell, rows.begin());
             HIP_TRY(d_ell_rows.upload(rows));
             std::vector<int32_t> pos_pad((size_t)npad, -1);
             std::copy(h_pos.begin(), h_pos.end(), pos_pad.begin());
             HIP_TRY(d_ell_pos.upload(pos_pad));
         }
-        HIP_TRY(d_col.upload(ec));
-        HIP_TRY(d_qval.upload(eq));
-        h_ell_q.swap(eq);
-        HIP_TRY(sumw.upload(hs_in));
-        HIP_TRY(pop.upload(hp));
+        HIP_TRY(hipMemset(d_long_rows.p, 0, sizeof(int32_t) * (size_t)(n_long ? n_long : 1)));
+        HIP_TRY(hipMemset(d_long_q.p, 0, sizeof(double) * long_alloc));
+        HIP_TRY(hipMemset(d_long_col.p, 0xff, sizeof(int32_t) * long_alloc));
+        HIP_TRY(hipMemset(sumw.p, 0, sizeof(double) * (size_t)npad));
+        HIP_TRY(hipMemset(pop.p, 0, sizeof(int32_t) * (size_t)npad));
+        // The arithmetic and the big copies happen on the device: row sums and normalised weights from the caller's CSR
+        // arrays, then the slot-major blocks of 64 rows and the compact copies of the longer rows.
+        DevBuf c_rp, c_col, c_val, c_pop, qcsr, sumw_rows, d_order;
+        HIP_TRY(c_rp.upload(h_rowptr));
+        HIP_TRY(c_col.ensure(sizeof(int32_t) * (nnz ? nnz : 1)));
+        HIP_TRY(c_val.ensure(sizeof(double) * (nnz ? nnz : 1)));
+        if (nnz) {
+            HIP_TRY(hipMemcpy(c_col.p, h_col.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c_val.p, h_val.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
+        }
+        HIP_TRY(c_pop.upload(std::vector<int32_t>(pop_, pop_ + n)));
+        HIP_TRY(qcsr.ensure(sizeof(double) * (nnz ? nnz : 1)));
+        HIP_TRY(sumw_rows.ensure(sizeof(double) * (size_t)n));
+        HIP_TRY(d_order.upload(order));
+        SparseBuildArgs sa{};
+        sa.n = n; sa.npad = npad;
+        sa.rowptr = c_rp.as<int32_t>(); sa.col = c_col.as<int32_t>(); sa.val = c_val.as<double>();
+        sa.qcsr = qcsr.as<double>(); sa.sumw_rows = sumw_rows.as<double>();
+        sa.order = d_order.as<int32_t>(); sa.n_ell = n_ell; sa.blocks = d_ell.as<EllBlock>();
+        sa.col_map = renumbered ? d_id_of.as<int32_t>() : nullptr;
+        sa.pop_in = c_pop.as<int32_t>(); sa.pop_out = pop.as<int32_t>(); sa.sumw_out = sumw.as<double>();
+        sa.ell_q = d_qval.as<double>(); sa.ell_col = d_col.as<int32_t>();
+        sa.n_long = n_long; sa.long_off = d_long_off.as<int32_t>();
+        sa.long_q = d_long_q.as<double>(); sa.long_col = d_long_col.as<int32_t>(); sa.long_rows_out = d_long_rows.as<int32_t>();
+        HIP_TRY(launch_sparse_normalise(sa, nullptr));
+        HIP_TRY(launch_sparse_fill(sa, n_blocks, nullptr));
+        HIP_TRY(hipDeviceSynchronize());   // the temporary buffers go out of scope
         return EPI_OK;
     }
 
@@ -901,6 +927,11 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
         G->seed_long = seed_long ? 1 : 0;
         std::vector<double> hq((size_t)nt * slots * (seed_long ? 1 : 64), 0.0), hs((size_t)nt, 0.0), row((size_t)(deg > 0 ? deg : 1));
         std::vector<double> qrow((size_t)std::max(64, slots), 0.0);
+        std::vector<double> seed_block_q;
+        if (!seed_long) {
+            rc = G->graph.download_block_q(sb, seed_block_q);
+            if (rc) return rc;
+        }
         for (int k = 0; k < d->n_travel; ++k) {
             if (!std::isfinite(d->travel[k]) || d->travel[k] < 0.0) return fail(EPI_ERR_BAD_ARGUMENT, "grid: travel scale %d = %g", k, d->travel[k]);
             double s = 0.0;
@@ -921,9 +952,7 @@ static int32_t grid_build(epi_grid* G, const epi_grid_desc* d) {
                 std::copy(qrow.begin(), qrow.begin() + slots, hq.begin() + (size_t)k * slots);
             } else {
                 double* blk = &hq[(size_t)k * slots * 64];
-                const int bs = G->graph.h_slots[sb];
-                for (int e = 0; e < bs; ++e)
-                    for (int l = 0; l < 64; ++l) blk[(size_t)e * 64 + l] = G->graph.h_ell_q[((size_t)G->graph.h_off[sb] + e) * 64 + l];
+                std::copy(seed_block_q.begin(), seed_block_q.end(), blk);   // whole slot groups of the block, the rest stays 0
                 for (int e = 0; e < slots; ++e) blk[(size_t)e * 64 + sl] = e < deg ? qrow[e] : 0.0;
             }
         }

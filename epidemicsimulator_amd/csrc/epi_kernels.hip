@@ -2367,6 +2367,83 @@ hipError_t launch_gravity_csr(const GravityCsrArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sparse graph tables on the device (SparseBuildArgs).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sparse_normalise_kernel(const SparseBuildArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const int rs = a.rowptr[i], re = a.rowptr[i + 1];
+    double sum = 0.0;
+    for (int k = rs; k < re; ++k) {
+        const double w = (a.col[k] == i) ? 0.0 : a.val[k];
+        sum = (k == rs) ? w : sum + w;      // left to right, as wRow.sum adds them
+    }
+    a.sumw_rows[i] = fmax(0.0, sum);
+    for (int k = rs; k < re; ++k) {
+        const double w = (a.col[k] == i) ? 0.0 : a.val[k];
+        a.qcsr[k] = (sum > 0.0) ? w / sum : 0.0;
+    }
+}
+
+// grid: n_blocks workgroups of 64 lanes for the ELL blocks, then n_long for the long rows, then ceil(n / 64) for the
+// per-patch tables.
+__global__ __launch_bounds__(64) void sparse_fill_kernel(const SparseBuildArgs a, int n_blocks) {
+    const int lane = threadIdx.x;
+    int item = blockIdx.x;
+    if (item < n_blocks) {
+        const int n_ell = a.n_ell;
+        const int p = item * 64 + lane;
+        const int i = p < n_ell ? a.order[p] : -1;
+        const int rs = i >= 0 ? a.rowptr[i] : 0, deg = i >= 0 ? a.rowptr[i + 1] - rs : 0;
+        const EllBlock blk = a.blocks[item];
+        const int slots = (blk.slots + kSlotGroup - 1) / kSlotGroup * kSlotGroup;
+        const size_t off = (size_t)blk.off;
+        for (int k = 0; k < slots; ++k) {
+            const bool has = k < deg;
+            const int c = has ? a.col[rs + k] : -1;
+            a.ell_q[(off + k) * 64 + lane] = has ? a.qcsr[rs + k] : 0.0;
+            a.ell_col[(off + k) * 64 + lane] = has ? (a.col_map ? a.col_map[c] : c) : -1;   // slots stay in the caller's column order
+        }
+        return;
+    }
+    item -= n_blocks;
+    if (item < a.n_long) {
+        const int n_ell = a.n_ell;
+        const int i = a.order[n_ell + item];
+        const int rs = a.rowptr[i], deg = a.rowptr[i + 1] - rs;
+        const size_t lo = (size_t)a.long_off[item];
+        // the compact copy spans whole groups of 64 slots up to the next row's copy: the host cleared it (0 / -1)
+        for (int k = lane; k < deg; k += 64) {
+            const int c = a.col[rs + k];
+            a.long_q[lo + k] = a.qcsr[rs + k];
+            a.long_col[lo + k] = a.col_map ? a.col_map[c] : c;
+        }
+        if (lane == 0) a.long_rows_out[item] = a.col_map ? a.col_map[i] : i;
+        return;
+    }
+    item -= a.n_long;
+    const int c = item * 64 + lane;
+    if (c < a.n) {
+        const int dst = a.col_map ? a.col_map[c] : c;
+        a.pop_out[dst] = a.pop_in[c];
+        a.sumw_out[dst] = a.sumw_rows[c];
+    }
+}
+
+hipError_t launch_sparse_normalise(const SparseBuildArgs& a, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sparse_normalise_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_sparse_fill(const SparseBuildArgs& a, int n_blocks, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)(n_blocks + a.n_long + (a.n + 63) / 64);
+    hipLaunchKernelGGL(sparse_fill_kernel, dim3(grid), dim3(64), 0, s, a, n_blocks);
+    return hipGetLastError();
+}
+
 hipError_t launch_gravity(const GravityArgs& a, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
     hipLaunchKernelGGL(gravity_rows_kernel, dim3((unsigned)a.n), dim3(256), 0, s, a);

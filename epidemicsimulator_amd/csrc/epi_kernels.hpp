@@ -290,6 +290,33 @@ struct GravityCsrArgs {
     int32_t* col; double* val;
 };
 hipError_t launch_gravity_csr(const GravityCsrArgs& a, hipStream_t s);
+
+// Table preparation of sparse graphs on the device, from the caller's CSR triple (columns ascending inside a row) and
+// the row order the host derived from the row lengths:
+//   normalise: per row the left-to-right sum of its stored off-diagonal weights (WorldToy.scala:113-114: the zeros of
+//     the entries that are not stored change no partial sum) and the normalised weights w / sumW (env.scala:244);
+//   fill:      the slot-major ELL arrays of the blocks of 64 rows and the compact copies of the long rows, columns
+//     translated through `col_map` (id_of when the engine renumbers the patches, NULL for the caller's numbering),
+//     and populations and row sums in the numbering the kernels run in.
+struct SparseBuildArgs {
+    int n, npad;
+    const int32_t* rowptr; const int32_t* col; const double* val;   // caller's CSR
+    double* qcsr;            // [nnz] normalised weights in CSR order
+    double* sumw_rows;       // [n] row sums by caller's row
+    const int32_t* order;    // [n] rows by position: the rows of at most kLaneSlots weights by length, then the long rows
+    int n_ell;               // rows held in the blocks
+    const EllBlock* blocks;  // [n_blocks] longest row and first slot of each block
+    const int32_t* col_map;  // NULL or id_of
+    const int32_t* pop_in;   // [n] caller's populations
+    int32_t* pop_out;        // [npad] populations by engine id (col_map) or caller's id
+    double* sumw_out;        // [npad]
+    double* ell_q; int32_t* ell_col;            // [total_slots][64]
+    int n_long; const int32_t* long_off;        // [n_long] first element of each long row's compact copy
+    double* long_q; int32_t* long_col;
+    int32_t* long_rows_out;  // [n_long] long rows in the numbering the kernels run in
+};
+hipError_t launch_sparse_normalise(const SparseBuildArgs& a, hipStream_t s);
+hipError_t launch_sparse_fill(const SparseBuildArgs& a, int n_blocks, hipStream_t s);
 hipError_t launch_gravity(const GravityArgs& a, hipStream_t s);
 hipError_t launch_world_pack(const WorldIoArgs& a, hipStream_t s);
 hipError_t launch_world_unpack(const WorldIoArgs& a, hipStream_t s);
