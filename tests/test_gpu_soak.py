@@ -19,7 +19,8 @@ def _tool(name):
 
 
 @pytest.mark.parametrize("name,seconds,seed,least", [("soak", 14.0, 11, 5), ("soak_world", 14.0, 12, 20),
-                                                     ("soak_train", 12.0, 13, 20), ("soak_learn", 12.0, 14, 50)])
+                                                     ("soak_train", 12.0, 13, 20), ("soak_learn", 12.0, 14, 50),
+                                                     ("soak_sweep_learn", 12.0, 15, 10)])
 def test_soak_slice(name, seconds, seed, least):
     import epidemicsimulator_amd as E
     assert E.lib().epi_device_count() >= 1, "no HIP device: GPU tests must run on the MI355X box"
