@@ -338,6 +338,13 @@ struct InflowWords {
 #ifndef EPI_CSR_THREADS
 #define EPI_CSR_THREADS 1024
 #endif
+// Sorting networks for 8, 10, ..., 24, 28 and 32 keys (1) or for 12, 16, 20, 24 and 32 only (0).  A block's rows are of
+// nearly one length (rows are sorted), and Batcher's network for 18 keys has 90 comparators against 132 for 24: measured on
+// the 20,000-patch sweep, degrees ~ Poisson(16): 16 / 24 / 32 only 0.747 of the roofline, five sizes 0.777, eleven 0.81
+// (same box, same call); one network per length up to 24 is 1 % slower again (code size).
+#ifndef EPI_CSR_MID_NETS
+#define EPI_CSR_MID_NETS 1
+#endif
 #ifndef EPI_CSR_TWO_PASS
 #define EPI_CSR_TWO_PASS 32   // routines of at least this many slots form the S and the I keys one after the other (0 = none)
 #endif
@@ -439,7 +446,8 @@ __device__ __forceinline__ LaneThreshold lane_threshold(uint32_t (&srt)[DMAX], i
 // Mobility split of one block of 64 rows, one lane per row, S and I in one sweep over the block's weights
 // (each weight is read twice per step: once for the keys, once with its column for the scatter).
 // A lane that exports nothing in a compartment runs along with E = 0: every product is 0, nothing is selected.
-template <int DMAX>
+// NS: the block's rows hold at most NS <= DMAX weights (the slots from NS on hold weight 0 and are neither read nor sorted).
+template <int DMAX, int NS = DMAX>
 __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI, int D, const double* __restrict__ qp,
                                                const int32_t* __restrict__ cp, int row, unsigned long long* sh_mov,
                                                int* sh_err, int t, long long* tm) {
@@ -448,6 +456,7 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
     constexpr int HALF = (DMAX % (2 * kSlotGroup) == 0) ? DMAX / 2 : kSlotGroup;
     const double EdS = (double)ES, EdI = (double)EI;
     EPI_TM(long long c0 = clock64();)
+    static_assert(NS <= DMAX && NS > DMAX - kSlotGroup, "NS lies in the last slot group");
     constexpr bool kTwoPass = EPI_CSR_TWO_PASS > 0 && DMAX >= EPI_CSR_TWO_PASS;
     LaneThreshold thS, thI;
     thI.Kx = 0xffffffffu;
@@ -457,7 +466,7 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
     // One compartment at a time: the keys of one compartment (DMAX registers) instead of two live side by side, at
     // the price of a third read of the block's weights in blocks that export infectious people.
     auto threshold_of = [&](double Ed, int32_t E) {
-        uint32_t key[DMAX];
+        uint32_t key[NS];
         uint32_t bsum = 0u;
 #pragma unroll
         for (int h0 = 0; h0 < DMAX; h0 += HALF) {
@@ -469,23 +478,25 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
                 if (h0 + k0 < D) {
                     const double* qg = group_ptr(qp, h0 + k0);
 #pragma unroll
-                    for (int j = 0; j < kSlotGroup; ++j) qv[k0 + j] = qg[j * 64];
+                    for (int j = 0; j < kSlotGroup; ++j)
+                        if (h0 + k0 + j < NS) qv[k0 + j] = qg[j * 64];
                 }
             }
 #pragma unroll
             for (int j = 0; j < HALF; ++j) {
+                if (h0 + j >= NS) continue;
                 const double raw = qv[j] * Ed;  // slots past D of a group that is read hold weight 0
                 bsum += (uint32_t)(int32_t)raw;
                 key[h0 + j] = (uint32_t)__double2hiint(frac_of(raw));
             }
         }
         const int32_t rem = (int32_t)((uint32_t)E - bsum);
-        return lane_threshold<DMAX>(key, rem, Ed, D, qp);
+        return lane_threshold<NS>(key, rem, Ed, D, qp);
     };
     thS = threshold_of(EdS, ES);
     if (anyI) thI = threshold_of(EdI, EI);
     } else {
-    uint32_t keyS[DMAX], keyI[DMAX];
+    uint32_t keyS[NS], keyI[NS];
     uint32_t bsumS = 0u, bsumI = 0u;
 #pragma unroll
     for (int h0 = 0; h0 < DMAX; h0 += HALF) {
@@ -497,12 +508,14 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
             if (h0 + k0 < D) {
                 const double* qg = group_ptr(qp, h0 + k0);
 #pragma unroll
-                for (int j = 0; j < kSlotGroup; ++j) qv[k0 + j] = qg[j * 64];
+                for (int j = 0; j < kSlotGroup; ++j)
+                    if (h0 + k0 + j < NS) qv[k0 + j] = qg[j * 64];
             }
         }
 #pragma unroll
         for (int j = 0; j < HALF; ++j) {
             const int k = h0 + j;
+            if (k >= NS) continue;
             const double rawS = qv[j] * EdS;  // slots past D of a group that is read hold weight 0
             bsumS += (uint32_t)(int32_t)rawS;
             keyS[k] = (uint32_t)__double2hiint(frac_of(rawS));
@@ -513,8 +526,8 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
     }
     const int32_t remS = (int32_t)((uint32_t)ES - bsumS), remI = (int32_t)((uint32_t)EI - bsumI);
     EPI_TM(asm volatile("" ::"v"(remS), "v"(remI)); { const long long c1 = clock64(); tm[0] += c1 - c0; c0 = c1; })
-    thS = lane_threshold<DMAX>(keyS, remS, EdS, D, qp);
-    if (anyI) thI = lane_threshold<DMAX>(keyI, remI, EdI, D, qp);
+    thS = lane_threshold<NS>(keyS, remS, EdS, D, qp);
+    if (anyI) thI = lane_threshold<NS>(keyI, remI, EdI, D, qp);
     }
     if (thS.bad || thI.bad) record_error(sh_err, EPI_ERR_UNSUPPORTED, row, t);
     EPI_TM(asm volatile("" ::"v"(thS.Kx), "v"(thI.Kx)); { const long long c1 = clock64(); tm[1] += c1 - c0; c0 = c1; })
@@ -537,6 +550,7 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
                         const int32_t* cg = group_ptr(cp, h0 + k0);
 #pragma unroll
                         for (int j = 0; j < kSlotGroup; ++j) {
+                            if (h0 + k0 + j >= NS) continue;
                             qv[k0 + j] = qg[j * 64];
                             cv[k0 + j] = cg[j * 64];
                         }
@@ -545,6 +559,7 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
 #pragma unroll
                 for (int j = 0; j < HALF; ++j) {
                     const int k = h0 + j;
+                    if (k >= NS) continue;
                     const double rawS = qv[j] * EdS;
                     uint32_t selS = (uint32_t)((uint32_t)__double2hiint(frac_of(rawS)) >= thS.Kx);
                     if constexpr (kPicked) selS |= (thS.picked >> k) & 1u;
@@ -952,13 +967,32 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                                                             : a.qval + off + lane;
                         const int32_t* __restrict__ cp = a.col + off + lane;
                         const bool anyI = __any(EIc > 0);
-                        // blocks are sorted by row length: the routine that fits the block's longest row
-                        if (DMAX >= 32 && D > 24)
-                            lane_apportion<(DMAX >= 32 ? 32 : DMAX)>(ESc, EIc, anyI, D, qp, cp, row, sh_mov, sh_err, t, tm);
-                        else if (DMAX >= 24 && D > 16)
-                            lane_apportion<(DMAX >= 24 ? 24 : DMAX)>(ESc, EIc, anyI, D, qp, cp, row, sh_mov, sh_err, t, tm);
-                        else
-                            lane_apportion<16>(ESc, EIc, anyI, D, qp, cp, row, sh_mov, sh_err, t, tm);
+                        // blocks are sorted by row length: the routine whose sorting network fits the block's longest row
+                        auto run = [&](auto ns) {
+                            constexpr int NS = decltype(ns)::value <= DMAX ? decltype(ns)::value : DMAX;
+                            lane_apportion<(NS + kSlotGroup - 1) / kSlotGroup * kSlotGroup, NS>(ESc, EIc, anyI, D, qp, cp, row, sh_mov,
+                                                                                               sh_err, t, tm);
+                        };
+                        using std::integral_constant;
+#if EPI_CSR_MID_NETS
+                        if (DMAX >= 32 && D > 28) run(integral_constant<int, 32>{});
+                        else if (DMAX >= 32 && D > 24) run(integral_constant<int, 28>{});
+                        else if (DMAX >= 24 && D > 22) run(integral_constant<int, 24>{});
+                        else if (DMAX >= 24 && D > 20) run(integral_constant<int, 22>{});
+                        else if (DMAX >= 24 && D > 18) run(integral_constant<int, 20>{});
+                        else if (DMAX >= 24 && D > 16) run(integral_constant<int, 18>{});
+                        else if (D > 14) run(integral_constant<int, 16>{});
+                        else if (D > 12) run(integral_constant<int, 14>{});
+                        else if (D > 10) run(integral_constant<int, 12>{});
+                        else if (D > 8) run(integral_constant<int, 10>{});
+                        else run(integral_constant<int, 8>{});
+#else
+                        if (DMAX >= 32 && D > 24) run(integral_constant<int, 32>{});
+                        else if (DMAX >= 24 && D > 20) run(integral_constant<int, 24>{});
+                        else if (DMAX >= 24 && D > 16) run(integral_constant<int, 20>{});
+                        else if (D > 12) run(integral_constant<int, 16>{});
+                        else run(integral_constant<int, 12>{});
+#endif
                     }
                 } else {
                     // a row longer than kLaneSlots: one wave with the dense kernel's routine on the compact
