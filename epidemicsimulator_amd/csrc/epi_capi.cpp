@@ -280,13 +280,16 @@ struct GraphTables {
         HIP_TRY(d_qval.ensure(sizeof(double) * ell_alloc));
         HIP_TRY(sumw.ensure(sizeof(double) * (size_t)npad));
         HIP_TRY(pop.ensure(sizeof(int32_t) * (size_t)npad));
+        {   // row of every lane of every block, -1 = no row (in the engine's numbering when the patches are renumbered:
+            // position p then holds patch p itself)
+            std::vector<int32_t> rows((size_t)(n_blocks > 0 ? n_blocks : 1) * 64, -1);
+            if (renumbered) for (int p = 0; p < n_ell; ++p) rows[(size_t)p] = p;
+            else std::copy(order.begin(), order.begin() + n_ell, rows.begin());
+            HIP_TRY(d_ell_rows.upload(rows));
+        }
         if (renumbered) {
-            d_ell_rows.release();
             d_ell_pos.release();
         } else {
-            std::vector<int32_t> rows((size_t)(n_blocks > 0 ? n_blocks : 1) * 64, -1);
-            std::copy(order.begin(), order.begin() + n_ell, rows.begin());
-            HIP_TRY(d_ell_rows.upload(rows));
             std::vector<int32_t> pos_pad((size_t)npad, -1);
             std::copy(h_pos.begin(), h_pos.end(), pos_pad.begin());
             HIP_TRY(d_ell_pos.upload(pos_pad));
@@ -333,6 +336,7 @@ struct GraphTables {
             ea.rowptr = d_rowptr.as<int32_t>(); ea.col = d_col.as<int32_t>(); ea.qval = d_qval.as<double>();
             ea.ell = d_ell.as<EllBlock>();
             ea.ell_rows = renumbered ? nullptr : d_ell_rows.as<int32_t>();
+            ea.block_rows = d_ell_rows.as<int32_t>();
             ea.ell_pos = renumbered ? nullptr : d_ell_pos.as<int32_t>();
             ea.n_blocks = n_blocks;
             ea.n_ell = n_ell;
@@ -1154,8 +1158,8 @@ EPI_API int32_t epi_grid_destroy(epi_grid* g) {
             }
             // phase timers of the sparse kernel (builds with -DEPI_CSR_TIMERS); they share slots with the histogram above
             if (h[0] == 0 && h[32] == 0 && (h[48] | h[51] | h[53]))
-                fprintf(stderr, "[epi cycles] pass1 %llu select %llu pass2 %llu | local+apply %llu barrier %llu mobility %llu barrier %llu\n",
-                        h[48], h[49], h[50], h[51], h[52], h[53], h[54]);
+                fprintf(stderr, "[epi cycles] pass1 %llu select %llu pass2 %llu | local+apply %llu barrier %llu mobility %llu barrier %llu | "
+                                "block set-up %llu\n", h[48], h[49], h[50], h[51], h[52], h[53], h[54], h[55]);
         }
     }
     delete g;

@@ -342,6 +342,9 @@ struct InflowWords {
 // nearly one length (rows are sorted), and Batcher's network for 18 keys has 90 comparators against 132 for 24: measured on
 // the 20,000-patch sweep, degrees ~ Poisson(16): 16 / 24 / 32 only 0.747 of the roofline, five sizes 0.777, eleven 0.81
 // (same box, same call); one network per length up to 24 is 1 % slower again (code size).
+#ifndef EPI_CSR_GRAB_AHEAD
+#define EPI_CSR_GRAB_AHEAD 1
+#endif
 #ifndef EPI_CSR_MID_NETS
 #define EPI_CSR_MID_NETS 1
 #endif
@@ -937,16 +940,30 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 return __builtin_amdgcn_readfirstlane(v);
             };
             int item = grab();
+#if EPI_CSR_GRAB_AHEAD
+            // The queue is asked two items ahead: the answer of the LDS counter (behind the other waves' scatter
+            // operations in the LDS pipe) arrives while the current item is worked on, not in front of it.
+            int next = grab();
+#endif
             const int b0 = item < nblocks ? item : 0;
             EllBlock blk = a.ell[b0];
             // patches numbered in lane-layout order (ell_rows == NULL): lane l of block b is patch 64 b + l itself
             const int32_t* __restrict__ expBS = a.ell_rows ? expPS : expS;
             const int32_t* __restrict__ expBI = a.ell_rows ? expPI : expI;
-            auto row_of = [&](int pos) { return a.ell_rows ? a.ell_rows[pos] : (pos < a.n_ell ? pos : -1); };
+            // always a table look-up, fetched a block ahead with the exports: computing the row where the patches are
+            // renumbered made two code paths write one register, and the wait the compiler puts in front of that
+            // covered the block record requested just before it -- a memory latency per block
+            auto row_of = [&](int pos) { return a.block_rows[pos]; };
             int row_n = row_of(b0 * 64 + lane);
             int32_t ES = expBS[b0 * 64 + lane], EI = expBI[b0 * 64 + lane];
             while (item < nitems) {
+#if EPI_CSR_GRAB_AHEAD
+                int after = 0;
+                if (lane == 0) after = atomicAdd(sh_next, 1);
+#else
                 const int next = grab();
+#endif
+                EPI_TM(const long long q0 = clock64();)
                 if (item < nblocks) {
                     const int b = item;
                     const EllBlock cur = blk;
@@ -969,6 +986,7 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                         const int32_t* __restrict__ cp = a.col + off + lane;
                         const bool anyI = __any(EIc > 0);
                         // blocks are sorted by row length: the routine whose sorting network fits the block's longest row
+                        EPI_TM(tm[7] += clock64() - q0;)
                         auto run = [&](auto ns) {
                             constexpr int NS = decltype(ns)::value <= DMAX ? decltype(ns)::value : DMAX;
                             lane_apportion<(NS + kSlotGroup - 1) / kSlotGroup * kSlotGroup, NS>(ESc, EIc, anyI, D, qp, cp, row, sh_mov,
@@ -1015,6 +1033,9 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                     }
                 }
                 item = next;
+#if EPI_CSR_GRAB_AHEAD
+                next = __builtin_amdgcn_readfirstlane(after);
+#endif
             }
         }
         EPI_TM({ const long long k1 = clock64(); tm[5] += k1 - k0; k0 = k1; })

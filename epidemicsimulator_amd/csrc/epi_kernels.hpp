@@ -45,6 +45,8 @@ struct EpisodeArgs {
     const int32_t* rowptr;    // [n+1] (marks sparse mode; row lengths)
     const EllBlock* ell;      // [n_blocks]
     const int32_t* ell_rows;  // [n_blocks][64] row of each lane, -1 = no row
+    const int32_t* block_rows;  // the same table, also present (position p -> p) when ell_rows is NULL: the mobility phase reads its
+                                // rows from it on one code path
     const int32_t* ell_pos;   // [npad] inverse: position 64*b + l of a row in the lane layout, -1 = long row
     int n_blocks;
     int n_ell;                // rows held in the blocks; with ell_rows == ell_pos == NULL row 64*b + l IS patch 64*b + l (patches numbered
