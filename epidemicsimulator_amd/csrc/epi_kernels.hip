@@ -342,6 +342,9 @@ struct InflowWords {
 // nearly one length (rows are sorted), and Batcher's network for 18 keys has 90 comparators against 132 for 24: measured on
 // the 20,000-patch sweep, degrees ~ Poisson(16): 16 / 24 / 32 only 0.747 of the roofline, five sizes 0.777, eleven 0.81
 // (same box, same call); one network per length up to 24 is 1 % slower again (code size).
+#ifndef EPI_CSR_KEEP_MAX
+#define EPI_CSR_KEEP_MAX 18
+#endif
 #ifndef EPI_CSR_GRAB_AHEAD
 #define EPI_CSR_GRAB_AHEAD 1
 #endif
@@ -465,6 +468,12 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
     thI.Kx = 0xffffffffu;
     thI.picked = 0u;
     thI.bad = false;
+    // Rows of up to EPI_CSR_KEEP_MAX weights keep their whole units and keys in registers for the scatter pass (4 NS
+    // registers) instead of reading the weights and forming both again.  Measured on the 20,000-patch sweep in one call:
+    // none 0.813, up to 12 weights 0.818, up to 16 0.845, up to 18 0.851 of the roofline; 20 spills 37 registers: 0.74.
+    constexpr bool kKeep = !kTwoPass && NS <= EPI_CSR_KEEP_MAX;
+    constexpr int NK = kKeep ? NS : 1;
+    uint32_t kS[NK], kI[NK], bS[NK], bI[NK];
     if constexpr (kTwoPass) {
     // One compartment at a time: the keys of one compartment (DMAX registers) instead of two live side by side, at
     // the price of a third read of the block's weights in blocks that export infectious people.
@@ -525,6 +534,10 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
             const double rawI = qv[j] * EdI;
             bsumI += (uint32_t)(int32_t)rawI;
             keyI[k] = (uint32_t)__double2hiint(frac_of(rawI));
+            if constexpr (kKeep) {
+                bS[k] = (uint32_t)(int32_t)rawS; kS[k] = keyS[k];
+                bI[k] = (uint32_t)(int32_t)rawI; kI[k] = keyI[k];
+            }
         }
     }
     const int32_t remS = (int32_t)((uint32_t)ES - bsumS), remI = (int32_t)((uint32_t)EI - bsumI);
@@ -578,8 +591,39 @@ __device__ __forceinline__ void lane_apportion(int32_t ES, int32_t EI, bool anyI
             }
         }
     };
-    if (__any((thS.picked | thI.picked) != 0u)) scatter(std::true_type{});
-    else scatter(std::false_type{});
+    auto scatter_kept = [&](auto with_picked) {
+        constexpr bool kPicked = decltype(with_picked)::value;
+        int cv[NS];
+#pragma unroll
+        for (int k0 = 0; k0 < DMAX; k0 += kSlotGroup) {
+#pragma unroll
+            for (int j = 0; j < kSlotGroup; ++j)
+                if (k0 + j < NS) cv[k0 + j] = 0;
+            if (k0 < D) {
+                const int32_t* cg = group_ptr(cp, k0);
+#pragma unroll
+                for (int j = 0; j < kSlotGroup; ++j)
+                    if (k0 + j < NS) cv[k0 + j] = cg[j * 64];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            uint32_t selS = (uint32_t)(kS[k < NK ? k : 0] >= thS.Kx);
+            if constexpr (kPicked) selS |= (thS.picked >> k) & 1u;
+            uint32_t selI = (uint32_t)(kI[k < NK ? k : 0] >= thI.Kx);
+            if constexpr (kPicked) selI |= (thI.picked >> k) & 1u;
+            const uint32_t allocS = bS[k < NK ? k : 0] + selS, allocI = bI[k < NK ? k : 0] + selI;
+            atomicAdd(&sh_mov[cv[k]], (unsigned long long)allocS | ((unsigned long long)allocI << 32));
+        }
+    };
+    const bool any_picked = __any((thS.picked | thI.picked) != 0u);
+    if constexpr (kKeep) {
+        if (any_picked) scatter_kept(std::true_type{});
+        else scatter_kept(std::false_type{});
+    } else {
+        if (any_picked) scatter(std::true_type{});
+        else scatter(std::false_type{});
+    }
     EPI_TM(__builtin_amdgcn_s_waitcnt(0); { const long long c1 = clock64(); tm[2] += c1 - c0; })
 }
 
