@@ -1378,6 +1378,7 @@ static int32_t grid_enqueue(epi_grid* g, int32_t g_begin, int32_t g_stride, int3
     ea.seed_idx = g->seed_idx; ea.n_travel = g->n_travel; ea.g_begin = g_begin; ea.g_stride = g_stride;
     ea.step_t_max = g->steps;  // world.stepOne(cfg.stepsPerEpoch), Calibrate.scala:70
     ea.validate = 1;
+    ea.uniform_clock = 1;      // every country starts from the one base state (Calibrate.scala:34-45)
     g->graph.fill(ea);
     ea.sumw_seed = g->sumw_seed.as<double>();
     if (g->graph.sparse) {

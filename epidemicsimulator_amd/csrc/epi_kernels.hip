@@ -817,6 +817,9 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
     typedef const __attribute__((address_space(4))) EpisodeArgs* KernArgs;
     const KernArgs kargs = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
 #endif
+    // the clock of a sweep's episode: one value for all patches (t advances by one in env.step and by one more, capped,
+    // in stepOne: env.scala:132, WorldToy.scala:135), read here and written back by the last pass of the launch
+    int tcu = a.uniform_clock ? a.tcur[eoff] : 0;
     // Step t: local dynamics (A), barrier, mobility (B), barrier, apply (C).  A thread owns the same patches
     // in A and C, so C of step t-1 and A of step t run as one pass over the thread's patches: the state of a
     // patch is read once and written once per step.
@@ -858,7 +861,7 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
             PatchIn p;
             p.s = ld4(kst, o4); p.i = ld4(kst, o4 + planeB); p.r = ld4(kst, o4 + 2u * planeB); p.d = ld4(kst, o4 + 3u * planeB);
             p.v = ld4(kst, o4 + 4u * planeB);
-            p.tc = ld4(ktc, o4);
+            p.tc = a.uniform_clock ? tcu : ld4(ktc, o4);
             p.es = p.ei = p.arr = p.pk = 0;
             p.pos = -1;
             p.ms = p.mi = 0u;
@@ -934,7 +937,7 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 st4(kst, o4 + 4u * planeB, o.v);
                 st8(kcap, o8, o.cap);
                 if (a.loc_s) { a.loc_s[eoff + c] = o.s; a.loc_i[eoff + c] = o.i; }
-                st4(ktc, o4, tc + 1);
+                if (!a.uniform_clock) st4(ktc, o4, tc + 1);
                 const int32_t eS = export_count(max(0, o.s), p.sw), eI = export_count(max(0, o.i), p.sw);
                 st4(kex, o4, eS);
                 st4(kex, o4 + planeB, eI);
@@ -949,6 +952,10 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 st4(kst, o4 + planeB, i0);
                 st4(ktc, o4, tc);
             }
+        }
+        if (a.uniform_clock) {
+            if (doC) tcu = min(tcu + 1, a.step_t_max);
+            if (doA) tcu += 1;
         }
         if (a.validate) {
             // per-thread partial sums stay below 2^44 (at most 40 patches of < 2^34 each per thread)

@@ -35,6 +35,8 @@ struct EpisodeArgs {
     int t_begin, t_end;
     int step_t_max;          // the tMax argument of stepOne (WorldToy.scala:135)
     int validate;
+    int uniform_clock;       // every patch of an episode carries the same clock (sweeps: one initial state for all): the sparse
+                             // kernel then keeps it in a register and writes the plane once, at the end of the launch
     const double* q;         // [n][npad]  w_ij / sumW_i, diagonal and padding 0
     const double* sumw;      // [npad]     max(0, sum_j wRow_j)  (WorldToy.scala:114)
     const double* qseed;     // [n_travel][npad] seed-row variants (ToyConn.scaleRow per travel scale)
