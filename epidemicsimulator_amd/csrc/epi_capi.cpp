@@ -1379,6 +1379,7 @@ static int32_t grid_enqueue(epi_grid* g, int32_t g_begin, int32_t g_stride, int3
     ea.step_t_max = g->steps;  // world.stepOne(cfg.stepsPerEpoch), Calibrate.scala:70
     ea.validate = 1;
     ea.uniform_clock = 1;      // every country starts from the one base state (Calibrate.scala:34-45)
+    ea.shared_actions = 1;     // the action table of a sweep holds one action per step (grid_build)
     g->graph.fill(ea);
     ea.sumw_seed = g->sumw_seed.as<double>();
     if (g->graph.sparse) {

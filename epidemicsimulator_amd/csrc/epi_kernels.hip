@@ -342,6 +342,12 @@ struct InflowWords {
 // nearly one length (rows are sorted), and Batcher's network for 18 keys has 90 comparators against 132 for 24: measured on
 // the 20,000-patch sweep, degrees ~ Poisson(16): 16 / 24 / 32 only 0.747 of the roofline, five sizes 0.777, eleven 0.81
 // (same box, same call); one network per length up to 24 is 1 % slower again (code size).
+#ifndef EPI_CSR_ACT_CONSTS
+#define EPI_CSR_ACT_CONSTS 1
+#endif
+#ifndef EPI_CSR_CAP_IF_CHANGED
+#define EPI_CSR_CAP_IF_CHANGED 1
+#endif
 #ifndef EPI_CSR_KEEP_MAX
 #define EPI_CSR_KEEP_MAX 18
 #endif
@@ -788,10 +794,10 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
     const int NP = a.npad;
     const size_t eoff = (size_t)e * NP;
     const size_t plane = (size_t)a.count * NP;
-    int32_t* __restrict__ expS = a.exports + 0 * plane + eoff;
-    int32_t* __restrict__ expI = a.exports + 1 * plane + eoff;
-    int32_t* __restrict__ expPS = a.exports + 2 * plane + eoff;  // the same two, indexed by lane-layout position
-    int32_t* __restrict__ expPI = a.exports + 3 * plane + eoff;
+    // export counts {susceptible, infectious} of every patch as one 8-byte pair (one store, one load where they are used),
+    // by patch in the first half of the scratch and by lane-layout position in the second
+    int2* __restrict__ expB = reinterpret_cast<int2*>(a.exports) + eoff;
+    int2* __restrict__ expP = reinterpret_cast<int2*>(a.exports + 2 * plane) + eoff;
 
     if (tid == 0) {
         sh_mass[0] = sh_mass[1] = sh_mass[2] = sh_mass[3] = 0ull;
@@ -831,7 +837,7 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
         const EpisodeArgs* ka = &a;
 #endif
         int32_t* const kst = ka->st + eoff;
-        int32_t* const kex = ka->exports + eoff;
+        int2* const kex = reinterpret_cast<int2*>(ka->exports) + eoff;
         int32_t* const ktc = ka->tcur + eoff;
         int32_t* const karr = ka->arrival + eoff;
         int32_t* const kpk = ka->peak + eoff;
@@ -840,6 +846,17 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
         const double* const kcst = ka->cst;
         const uint32_t planeB = (uint32_t)(plane * sizeof(int32_t)), np8 = (uint32_t)NP * 8u;
         const bool doC = t > a.t_begin, doA = t < a.t_end;
+#if EPI_CSR_ACT_CONSTS
+        // row of the constants table the step's action reads: -1 none, -2 unknown (actions differ by patch: fetch all)
+        int act_cst = -2, shared_act = 0;
+        if (a.shared_actions && !ka->act_episode && doA) {
+            int sa = (int)ka->actions[(size_t)(t - ka->act_t0) * NP];
+            sa = __builtin_amdgcn_readfirstlane(sa < 0 ? 0 : (sa > 7 ? 7 : sa));
+            shared_act = sa;
+            act_cst = sa == 1 ? CST_EFF1 : sa == 2 ? CST_EFF2 : sa == 3 ? CST_EFF3 : sa == 5 ? CST_SURGE : sa == 6 ? CST_VAX6
+                      : sa == 7 ? CST_VAX7 : -1;
+        }
+#endif
         EPI_TM(long long k0 = clock64();)
         if (tid == 0) *sh_next = 0;
         unsigned long long mass_local = 0ull, mass_move = 0ull;
@@ -870,7 +887,7 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
             if (doC) {
                 const unsigned long long cell = sh_mov[c];
                 p.ms = (uint32_t)cell; p.mi = (uint32_t)(cell >> 32);
-                p.es = ld4(kex, o4); p.ei = ld4(kex, o4 + planeB);
+                { const int2 ex = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(kex) + o8); p.es = ex.x; p.ei = ex.y; }
                 p.arr = ld4(karr, o4); p.pk = ld4(kpk, o4);
             }
             if (doA) {
@@ -878,12 +895,26 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 p.k.gamma = ld8(kcst, o8 + CST_GAMMA * np8);
                 p.k.ifr0 = ld8(kcst, o8 + CST_IFR0 * np8);
                 p.k.cnoise = ld8(kcst, o8 + CST_CNOISE * np8);
+#if EPI_CSR_ACT_CONSTS
+                if (act_cst >= 0) {   // the one constant the step's shared action uses
+                    const double x = ld8(kcst, o8 + (uint32_t)act_cst * np8);
+                    p.k.eff1 = p.k.eff2 = p.k.eff3 = p.k.surge = p.k.vax6 = p.k.vax7 = x;
+                } else if (act_cst == -1) {   // none
+                    p.k.eff1 = p.k.eff2 = p.k.eff3 = p.k.surge = p.k.vax6 = p.k.vax7 = 0.0;
+                } else
+#endif
+                {
                 p.k.eff1 = ld8(kcst, o8 + CST_EFF1 * np8);
                 p.k.eff2 = ld8(kcst, o8 + CST_EFF2 * np8);
                 p.k.eff3 = ld8(kcst, o8 + CST_EFF3 * np8);
                 p.k.surge = ld8(kcst, o8 + CST_SURGE * np8);
                 p.k.vax6 = ld8(kcst, o8 + CST_VAX6 * np8);
                 p.k.vax7 = ld8(kcst, o8 + CST_VAX7 * np8);
+                }
+#if EPI_CSR_ACT_CONSTS
+                if (act_cst != -2) p.act = shared_act;
+                else
+#endif
                 p.act = ka->act_episode ? (int)ka->act_episode[eoff + c] : (int)ka->actions[(size_t)(t - ka->act_t0) * NP + c];
                 p.z = ka->noise_episode ? ld8(ka->noise_episode + eoff, o8) : ld8(ka->noise + (size_t)(t - ka->noise_t0) * NP, o8);
                 p.cap = ld8(kcap, o8);
@@ -933,18 +964,18 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                 if (a.validate && ta != tb) record_error(sh_err, EPI_ERR_LOCAL_MASS, (int)c, tc);
                 if ((o.s | o.i | o.r | o.d | o.v) < 0) record_error(sh_err, EPI_ERR_INT_RANGE, (int)c, tc);
                 if (a.rwd) a.reward_out[eoff + c] = reward_of(a.rwd[c], (double)i0, (double)d0, o, act);
-                st4(kst, o4, o.s); st4(kst, o4 + planeB, o.i); st4(kst, o4 + 2u * planeB, o.r); st4(kst, o4 + 3u * planeB, o.d);
+                st4(kst, o4, o.s); st4(kst, o4 + planeB, o.i);
+                st4(kst, o4 + 2u * planeB, o.r); st4(kst, o4 + 3u * planeB, o.d);
                 st4(kst, o4 + 4u * planeB, o.v);
-                st8(kcap, o8, o.cap);
+#if EPI_CSR_CAP_IF_CHANGED
+                if (o.cap != p.cap)   // hospCap changes under SurgeCare only (env.scala:76)
+#endif
+                    st8(kcap, o8, o.cap);
                 if (a.loc_s) { a.loc_s[eoff + c] = o.s; a.loc_i[eoff + c] = o.i; }
                 if (!a.uniform_clock) st4(ktc, o4, tc + 1);
                 const int32_t eS = export_count(max(0, o.s), p.sw), eI = export_count(max(0, o.i), p.sw);
-                st4(kex, o4, eS);
-                st4(kex, o4 + planeB, eI);
-                if (p.pos >= 0) {  // second copy where the mobility phase reads it with coalesced loads
-                    expPS[p.pos] = eS;
-                    expPI[p.pos] = eI;
-                }
+                *reinterpret_cast<int2*>(reinterpret_cast<char*>(kex) + o8) = make_int2(eS, eI);
+                if (p.pos >= 0) expP[p.pos] = make_int2(eS, eI);  // second copy where the mobility phase reads it with coalesced loads
                 sh_mov[c] = 0ull;
                 mass_local += ta > 0 ? (unsigned long long)ta : 0ull;
             } else {
@@ -999,14 +1030,13 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
             const int b0 = item < nblocks ? item : 0;
             EllBlock blk = a.ell[b0];
             // patches numbered in lane-layout order (ell_rows == NULL): lane l of block b is patch 64 b + l itself
-            const int32_t* __restrict__ expBS = a.ell_rows ? expPS : expS;
-            const int32_t* __restrict__ expBI = a.ell_rows ? expPI : expI;
+            const int2* __restrict__ expBlk = a.ell_rows ? expP : expB;
             // always a table look-up, fetched a block ahead with the exports: computing the row where the patches are
             // renumbered made two code paths write one register, and the wait the compiler puts in front of that
             // covered the block record requested just before it -- a memory latency per block
             auto row_of = [&](int pos) { return a.block_rows[pos]; };
             int row_n = row_of(b0 * 64 + lane);
-            int32_t ES = expBS[b0 * 64 + lane], EI = expBI[b0 * 64 + lane];
+            int2 EX = expBlk[b0 * 64 + lane];
             while (item < nitems) {
 #if EPI_CSR_GRAB_AHEAD
                 int after = 0;
@@ -1019,13 +1049,12 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                     const int b = item;
                     const EllBlock cur = blk;
                     const int row = row_n;
-                    const int32_t ESc = row >= 0 ? ES : 0, EIc = row >= 0 ? EI : 0;
+                    const int32_t ESc = row >= 0 ? EX.x : 0, EIc = row >= 0 ? EX.y : 0;
                     {
                         const int bn = next < nblocks ? next : b;
                         blk = a.ell[bn];
                         row_n = row_of(bn * 64 + lane);
-                        ES = expBS[bn * 64 + lane];
-                        EI = expBI[bn * 64 + lane];
+                        EX = expBlk[bn * 64 + lane];
                     }
                     const int D = __builtin_amdgcn_readfirstlane(cur.slots);  // same for the whole block
                     if (__any((ESc | EIc) != 0) && D > 0) {
@@ -1069,8 +1098,9 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
                     // row (whole groups of 64 slots, zero padded), scattered through the row's column list
                     const int o = item - nblocks;
                     const int row = a.long_rows[o];
-                    const int32_t ESl = __builtin_amdgcn_readfirstlane(expS[row]);
-                    const int32_t EIl = __builtin_amdgcn_readfirstlane(expI[row]);
+                    const int2 exl = expB[row];
+                    const int32_t ESl = __builtin_amdgcn_readfirstlane(exl.x);
+                    const int32_t EIl = __builtin_amdgcn_readfirstlane(exl.y);
                     if ((ESl | EIl) != 0) {
                         const int deg = a.rowptr[row + 1] - a.rowptr[row];
                         const int32_t* __restrict__ crow = a.long_col + a.long_off[o];

@@ -35,6 +35,9 @@ struct EpisodeArgs {
     int t_begin, t_end;
     int step_t_max;          // the tMax argument of stepOne (WorldToy.scala:135)
     int validate;
+    int shared_actions;      // `actions[t][*]` holds one value per step (a sweep's agents share seed and hyper-parameters, so they
+                             // draw the same exploratory action: DDQNAgent.scala:14): the sparse kernel then fetches only the
+                             // constant that action uses
     int uniform_clock;       // every patch of an episode carries the same clock (sweeps: one initial state for all): the sparse
                              // kernel then keeps it in a register and writes the plane once, at the end of the launch
     const double* q;         // [n][npad]  w_ij / sumW_i, diagonal and padding 0
@@ -67,8 +70,8 @@ struct EpisodeArgs {
     const int32_t* long_off;  // [n_long] first element of the row's compact copy in long_q / long_col
     const double* long_q;     // compact copies: a row of deg weights occupies 64 * dense_slots_for(deg) elements
     const int32_t* long_col;  // same shape, -1 = padding
-    int32_t* exports;        // [4][count][npad] scratch of the sparse kernel: exportS / exportI by patch, then the
-                             // same two by position in the lane layout
+    int32_t* exports;        // [4][count][npad] words of scratch of the sparse kernel (8-byte aligned): pairs {exportS, exportI}
+                             // by patch in the first half, the same pairs by position in the lane layout in the second
     const double* qtop;      // [n][kTopWeights] each row's largest normalised weights, descending (or NULL)
     const double* qtop_seed; // [n_travel][kTopWeights]
     const double* beta0;     // [n_beta][npad] or [1][npad]
