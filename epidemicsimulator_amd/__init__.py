@@ -996,20 +996,41 @@ class WorldToy:
 # ------------------------------------------------------------------------------------------------
 # Calibrate.scala
 # ------------------------------------------------------------------------------------------------
+class ProfileTable:
+    """Country profiles already marshalled into the C ABI's array of epi_profile records (and the populations into an
+    int32 array): built once, it can be handed to any number of engines in place of the list of profile objects --
+    marshalling 20,000 Python objects costs several times what epi_grid_create itself does."""
+
+    def __init__(self, profiles, pops=None):
+        self.n = len(profiles)
+        self.array = (_capi.Profile * self.n)(*[p._c() if hasattr(p, "_c") else _capi.Profile(*p) for p in profiles])
+        self.pops = i32(pops) if pops is not None else None
+
+    def __len__(self):
+        return self.n
+
+
 def _grid_desc(hp, steps, base, seed_idx, pops, conn, profiles, betas, travel, t_arrive, t_peak, heterogeneous, device,
                names=None):
     """Fills an epi_grid_desc; returns it with the arrays it points into (keep them alive while it is used).
     `names` (country names) decide the learningIntensity of WorldToy.scala:157-162 for rollouts that learn."""
     n = len(pops)
-    pops = i32(pops)
+    pops = profiles.pops if isinstance(profiles, ProfileTable) and profiles.pops is not None and pops is profiles.pops else i32(pops)
     dense, rp, col, val = _csr_or_dense(conn)
-    prof_arr = (_capi.Profile * n)(*[p._c() if hasattr(p, "_c") else _capi.Profile(*p) for p in profiles])
+    if isinstance(profiles, ProfileTable):
+        if len(profiles) != n:
+            raise ValueError("ProfileTable of %d profiles for %d countries" % (len(profiles), n))
+        prof_arr = profiles.array
+    else:
+        prof_arr = (_capi.Profile * n)(*[p._c() if hasattr(p, "_c") else _capi.Profile(*p) for p in profiles])
     ta = np.zeros(n); tp = np.zeros(n)
     ha = np.zeros(n, dtype=np.uint8); hk = np.zeros(n, dtype=np.uint8)
-    for c, v in (t_arrive or {}).items():
-        ta[c], ha[c] = v, 1
-    for c, v in (t_peak or {}).items():
-        tp[c], hk[c] = v, 1
+    if t_arrive:
+        idx = np.fromiter(t_arrive.keys(), dtype=np.int64, count=len(t_arrive))
+        ta[idx] = np.fromiter(t_arrive.values(), dtype=np.float64, count=len(t_arrive)); ha[idx] = 1
+    if t_peak:
+        idx = np.fromiter(t_peak.keys(), dtype=np.int64, count=len(t_peak))
+        tp[idx] = np.fromiter(t_peak.values(), dtype=np.float64, count=len(t_peak)); hk[idx] = 1
     d = _capi.GridDesc()
     d.n, d.pop = n, ptr(pops, C.c_int32)
     d.conn = ptr(dense, C.c_double) if dense is not None else None

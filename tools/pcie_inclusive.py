@@ -12,14 +12,16 @@ for name in sys.argv[1:] or ["c3"]:
     n, T = len(wl["countries"]), wl["steps"]
     G = len(wl["betas"]) * len(wl["travel"])
     base = synth.base_state(T)
-    for rep in range(2):
+    pops = [c.pop for c in wl["countries"]]
+    table = E.ProfileTable(wl["profiles"], pops)   # what a caller holds between engines (a JVM shim: one MemorySegment)
+    for rep in range(3):
         t0 = time.perf_counter()
-        eng = E.GridEngine(E.HyperParams(), T, base, wl["seed_idx"], [c.pop for c in wl["countries"]], wl["conn"], wl["profiles"],
+        eng = E.GridEngine(E.HyperParams(), T, base, wl["seed_idx"], table.pops if rep else pops, wl["conn"], table if rep else wl["profiles"],
                            wl["betas"], wl["travel"], wl["t_arrive"], wl["t_peak"], True)
         t1 = time.perf_counter()
         out = eng.run(want_metrics=False)
         best = E.grid_argmin(out["loss"])
         t2 = time.perf_counter()
         eng.close()
-        print("%s rep %d: create %.1f ms, sweep+download+argmin %.1f ms, end to end %.4g country-steps/s" %
-              (name, rep, (t1 - t0) * 1e3, (t2 - t1) * 1e3, G * n * T / (t2 - t0)))
+        print("%s rep %d (%s): create %.1f ms, sweep+download+argmin %.1f ms, end to end %.4g country-steps/s" %
+              (name, rep, "profile table" if rep else "profile objects", (t1 - t0) * 1e3, (t2 - t1) * 1e3, G * n * T / (t2 - t0)))
