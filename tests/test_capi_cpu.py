@@ -197,3 +197,29 @@ def test_surface_csv_is_what_the_heatmap_script_reads(epi, tmp_path):
     with pytest.raises(ValueError):
         (tmp_path / "bad.csv").write_text("a,b\n1,2\n")
         epi.Calibrate.read_surface_csv(str(tmp_path / "bad.csv"))
+
+
+def test_profile_table_fills_the_same_descriptor(epi):
+    """A ProfileTable (profiles marshalled once, kept between engines) must give byte for byte the descriptor arrays that
+    the list of profile objects gives: populations, epi_profile records, targets."""
+    import ctypes as C
+    from epidemicsimulator_amd import synth
+    import epidemicsimulator_amd as E
+    wl = synth.small_workload(37, 2, 3, 20, seed=11)
+    pops = [c.pop for c in wl["countries"]]
+    args = (E.HyperParams(), 20, synth.base_state(20), 0)
+    tail = (wl["conn"],)
+    d1, keep1 = E._grid_desc(*args, pops, wl["conn"], wl["profiles"], E.f64(wl["betas"]), E.f64(wl["travel"]),
+                             wl["t_arrive"], wl["t_peak"], True, 0)
+    table = E.ProfileTable(wl["profiles"], pops)
+    d2, keep2 = E._grid_desc(*args, table.pops, wl["conn"], table, E.f64(wl["betas"]), E.f64(wl["travel"]),
+                             wl["t_arrive"], wl["t_peak"], True, 0)
+    n = len(pops)
+    assert d1.n == d2.n == n
+    assert C.string_at(d1.prof, n * C.sizeof(E._capi.Profile)) == C.string_at(d2.prof, n * C.sizeof(E._capi.Profile))
+    assert C.string_at(d1.pop, 4 * n) == C.string_at(d2.pop, 4 * n)
+    for f, w in (("t_arrive", 8), ("t_peak", 8), ("has_arrive", 1), ("has_peak", 1)):
+        assert C.string_at(getattr(d1, f), w * n) == C.string_at(getattr(d2, f), w * n), f
+    assert sum(C.string_at(d1.has_arrive, n)) == len(wl["t_arrive"])
+    with pytest.raises(ValueError):
+        E._grid_desc(*args, pops[:-1], wl["conn"], table, E.f64(wl["betas"]), E.f64(wl["travel"]), {}, {}, True, 0)
