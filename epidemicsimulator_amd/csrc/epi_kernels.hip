@@ -1149,22 +1149,24 @@ __global__ __launch_bounds__(kCsrThreads) void episode_csr_kernel(const EpisodeA
 // ---------------------------------------------------------------------------------------------
 constexpr int kTinyN = 16;
 
-__device__ __forceinline__ void tiny_split(int32_t E, const double (&q)[kTinyN], const double* __restrict__ qrow, int n, int c,
+// TN: columns a lane holds and sorts (8 for worlds of at most eight countries -- 19 comparators instead of 63 -- else 16)
+template <int TN>
+__device__ __forceinline__ void tiny_split(int32_t E, const double (&q)[TN], const double* __restrict__ qrow, int n, int c,
                                            uint32_t* sh_mov) {
     if (!__any(E > 0)) return;
     const double Ed = (double)E;
-    uint32_t srt[kTinyN];
+    uint32_t srt[TN];
     uint32_t bsum = 0u;
 #pragma unroll
-    for (int j = 0; j < kTinyN; ++j) {
+    for (int j = 0; j < TN; ++j) {
         const double raw = q[j] * Ed;
         bsum += (uint32_t)(int32_t)raw;
         srt[j] = (uint32_t)__double2hiint(frac_of(raw));
     }
     const int32_t rem = E > 0 ? (int32_t)((uint32_t)E - bsum) : 0;
-    const LaneThreshold th = lane_threshold<kTinyN, 1, false>(srt, rem, Ed, n, qrow);  // a dense row: zero fractions take units too
+    const LaneThreshold th = lane_threshold<TN, 1, false>(srt, rem, Ed, n, qrow);  // a dense row: zero fractions take units too
 #pragma unroll
-    for (int j = 0; j < kTinyN; ++j) {
+    for (int j = 0; j < TN; ++j) {
         const double raw = q[j] * Ed;
         const uint32_t sel = (uint32_t)((uint32_t)__double2hiint(frac_of(raw)) >= th.Kx) | ((th.picked >> j) & 1u);
         const uint32_t alloc = (uint32_t)(int32_t)raw + (j < n ? sel : 0u);
@@ -1172,6 +1174,7 @@ __device__ __forceinline__ void tiny_split(int32_t E, const double (&q)[kTinyN],
     }
 }
 
+template <int TN>
 __global__ __launch_bounds__(64) void episode_tiny_kernel(const EpisodeArgs a) {
     __shared__ uint32_t sh_movS[4][kTinyN], sh_movI[4][kTinyN];
     __shared__ unsigned long long sh_mass[4][2];
@@ -1199,9 +1202,9 @@ __global__ __launch_bounds__(64) void episode_tiny_kernel(const EpisodeArgs a) {
     const bool seed_row = (cc == a.seed_idx && a.qseed);
     const double* __restrict__ qrow = seed_row ? a.qseed + (size_t)ti * NP : a.q + (size_t)cc * NP;
     const double my_sumw = real ? (seed_row ? a.sumw_seed[ti] : a.sumw[cc]) : 0.0;
-    double q[kTinyN];
+    double q[TN];
 #pragma unroll
-    for (int j = 0; j < kTinyN; ++j) q[j] = real ? qrow[j] : 0.0;
+    for (int j = 0; j < TN; ++j) q[j] = real ? qrow[j] : 0.0;
     StepConsts k;
     k.beta0 = a.beta0[(size_t)bi * NP + cc];
     k.gamma = a.cst[CST_GAMMA * NP + cc];
@@ -1255,8 +1258,8 @@ __global__ __launch_bounds__(64) void episode_tiny_kernel(const EpisodeArgs a) {
         if (a.validate && mass_local) atomicAdd(&sh_mass[grp][0], mass_local);
         __syncthreads();
         // ---- B: mobility (WorldToy.scala:106-126), every lane splits its own row
-        tiny_split(eS, q, qrow, n, c, sh_movS[grp]);
-        tiny_split(eI, q, qrow, n, c, sh_movI[grp]);
+        tiny_split<TN>(eS, q, qrow, n, c, sh_movS[grp]);
+        tiny_split<TN>(eI, q, qrow, n, c, sh_movI[grp]);
         __syncthreads();
         // ---- C: apply, metrics, world mass (WorldToy.scala:128-145)
         unsigned long long mass_move = 0ull;
@@ -1346,7 +1349,8 @@ hipError_t launch_episode(const EpisodeArgs& a, hipStream_t s) {
         return hipErrorInvalidValue;
     }
     if (a.n <= kTinyN && a.npad == 64) {
-        hipLaunchKernelGGL(episode_tiny_kernel, dim3((unsigned)((a.count + 3) / 4)), dim3(64), 0, s, a);
+        if (a.n <= 8) hipLaunchKernelGGL(episode_tiny_kernel<8>, dim3((unsigned)((a.count + 3) / 4)), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(episode_tiny_kernel<kTinyN>, dim3((unsigned)((a.count + 3) / 4)), dim3(64), 0, s, a);
         return hipGetLastError();
     }
     const dim3 grid((unsigned)a.count);
