@@ -612,10 +612,9 @@ def test_grid_full_size_properties(epi):
         np.testing.assert_array_equal(one["arrival"][0], out["arrival"][g])
         np.testing.assert_array_equal(one["peak"][0], out["peak"][g])
     eng.close()
-    # 48 grid points of the full-size configuration against the oracle: six beta rows (first and last among them) x
-    # eight travel scales -- first, last, and scales on either side of the point (row sum x ts = 0.2) where the cap of
-    # ToyConn.scaleRow starts to change the seed row (ToyConn.scala:63-66)
-    pts = [(b, t) for b in (0, 5, 12, 19, 26, 31) for t in (0, 3, 11, 22, 24, 27, 30, 31)]
+    # the whole full-size surface (all 1,024 grid points) against the oracle; the travel scales lie on either side of the
+    # point (row sum x ts = 0.2) where the cap of ToyConn.scaleRow starts to change the seed row (ToyConn.scala:63-66)
+    pts = [(b, t) for b in range(32) for t in range(32)]
     assert not util.seed_row_cap_binds(wl, 22) and util.seed_row_cap_binds(wl, 27) and util.seed_row_cap_binds(wl, 31)
     want = util.oracle_points(wl, base, pts)
     flat = [b * 32 + t for b, t in pts]
@@ -626,7 +625,7 @@ def test_grid_full_size_properties(epi):
 
 def test_grid_full_size_c3(epi):
     """Configuration 3 at full size (1,000 countries, 64x64, T=200): the same size-independent properties, slabs
-    of the flat grid as the 8-GPU run cuts them, and one grid point against the oracle."""
+    of the flat grid as the 8-GPU run cuts them, and 64 grid points against the oracle."""
     from epidemicsimulator_amd import synth
     from epidemicsimulator_amd.dist import slab_bounds
     wl = synth.workload("c3")
@@ -641,9 +640,10 @@ def test_grid_full_size_c3(epi):
     np.testing.assert_array_equal(slab["loss"], out["loss"][g0:g0 + cnt])
     assert (slab["arrival"] >= 0).all() and (slab["arrival"] <= wl["steps"]).all() and (slab["arrival"][:, 0] == 0).all()
     eng.close()
-    # 32 grid points against the oracle (sixteen at a time, one thread each): eight beta rows, first and last among them, x travel scales first / one
-    # below and one above the point where ToyConn.scaleRow's 0.2 row-sum cap binds (ToyConn.scala:63-66) / last
-    pts = [(b, t) for b in (0, 9, 21, 30, 37, 46, 55, 63) for t in (0, 50, 56, 63)]
+    # 64 grid points against the oracle (sixteen at a time, one thread each): eight beta rows, first and last among them,
+    # x eight travel scales -- first, last, and scales below and above the point where ToyConn.scaleRow's 0.2 row-sum cap
+    # binds (ToyConn.scala:63-66)
+    pts = [(b, t) for b in (0, 9, 21, 30, 37, 46, 55, 63) for t in (0, 12, 27, 41, 50, 56, 60, 63)]
     assert not util.seed_row_cap_binds(wl, 50) and util.seed_row_cap_binds(wl, 56) and util.seed_row_cap_binds(wl, 63)
     want = util.oracle_points(wl, base, pts)
     eng = epi.GridEngine(epi.HyperParams(), wl["steps"], base, 0, [c.pop for c in wl["countries"]], wl["conn"],
@@ -659,7 +659,7 @@ def test_grid_full_size_c3(epi):
 
 def test_grid_full_size_c4(epi):
     """Configuration 4 at full size (20,000 patches, CSR, 16x16, T=200): properties and slab invariance on the
-    whole sweep, and three grid points over all 200 steps against the oracle's CSR world."""
+    whole sweep, and 64 of the 256 grid points over all 200 steps against the oracle's CSR world."""
     from epidemicsimulator_amd import synth
     wl = synth.workload("c4")
     n = len(wl["countries"])
@@ -676,8 +676,9 @@ def test_grid_full_size_c4(epi):
         np.testing.assert_array_equal(one["arrival"][0], out["arrival"][g])
         np.testing.assert_array_equal(one["peak"][0], out["peak"][g])
     eng.close()
-    # three grid points (first, middle, last beta row; different travel scales) for all 200 steps against the oracle's CSR world
-    pts = [(0, 3), (9, 4), (15, 15)]
+    # a quarter of the grid (eight beta rows, first and last among them, x eight travel scales: 64 points) for all 200
+    # steps against the oracle's CSR world
+    pts = [(b, t) for b in (0, 2, 5, 7, 9, 11, 13, 15) for t in (0, 1, 3, 6, 8, 10, 13, 15)]
     want = util.oracle_points(wl, base, pts, sparse=True)
     flat = [b * 16 + t for b, t in pts]
     np.testing.assert_array_equal(out["arrival"][flat], want["arrival"])
